@@ -1,0 +1,265 @@
+/* rt_abi.h — the drop-in boundary: C ABI of the MI355X render library (librt_hip.so).
+ *
+ * This is what replaces the body of the reference's
+ *     pub fn render(&self, world: &World) -> Canvas          (src/camera.rs:66-84)
+ * The reference-side host (Rust; the C++ mirror in
+ * raytracer_amd/csrc/host in this repo) flattens `World` into the plain arrays below and calls
+ * rt_scene_create + rt_render.  Plain pointers and sizes only; no C++/torch types.
+ *
+ * Conventions
+ *  - all floats are IEEE f32, little-endian; all indices are 32-bit;
+ *  - every array is caller-owned and only read during the call that receives it
+ *    (rt_scene_create copies the scene into HBM; the handle keeps no host pointers);
+ *  - functions return RT_OK (0) or a negative RT_E_* code, never throw or abort;
+ *    rt_last_error() returns a message for the last failure on that context;
+ *  - a context is bound to one GPU and is single-threaded (one call at a time).
+ *
+ * Layout rules that make the device results equal to the reference's:
+ *  - shapes are stored in the reference's INSERTION ORDER (World::intersect gather order,
+ *    src/world.rs:44-62: csg leaves, then groups depth-first shapes-before-children
+ *    (src/groups.rs:118-123), then loose shapes); the index of a shape is its tie-break rank
+ *    and its object id;
+ *  - group nodes are the reference's groups verbatim, depth-first, with the bounding boxes the
+ *    reference itself would compute (src/groups.rs:166-188 incl. its quirks) — never rebuilt;
+ *  - transforms are the exact cofactor inverses (src/matrices.rs:185-197), rows 0..2 only:
+ *    Mul<Point>/Mul<Vector> discard the w row (src/matrices.rs:220-236).
+ */
+#ifndef RT_ABI_H
+#define RT_ABI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_ABI_VERSION 1u
+
+enum {
+  RT_OK = 0,
+  RT_E_ABI = -1,     /* version/size mismatch, NULL argument */
+  RT_E_DEVICE = -2,  /* HIP error */
+  RT_E_OOM = -3,     /* device allocation failed */
+  RT_E_SCENE = -4,   /* scene violates a device limit (chain depth, csg depth, ...) */
+  RT_E_OVERFLOW = -5 /* a per-ray intersection list overflowed its capacity; image is invalid */
+};
+
+/* shape kinds — order of the reference enum (src/shapes.rs:27-36) */
+enum { RT_SPHERE = 0, RT_PLANE, RT_CUBE, RT_CYLINDER, RT_CONE, RT_TRIANGLE, RT_SMOOTH_TRIANGLE };
+#define RT_SHAPE_KIND_MASK 0xFu
+#define RT_SHAPE_SHADOW 0x10u /* Shape::shadow() (src/shapes.rs:294-304) */
+#define RT_SHAPE_CLOSED 0x20u /* cylinder/cone `closed` */
+#define RT_VCLASS_NEVER 0xFFFFFFFFu /* shape holds a NaN: it is != every shape, itself included */
+
+/* rows 0..2 of an exact inverse transform, row-major; entry 0 of the table is the identity */
+typedef struct {
+  float m[12];
+} RtXform;
+
+/* One shape (32 B). Replaces the by-value `Shape` enum (src/shapes.rs:27-36). */
+typedef struct {
+  uint32_t kind_flags; /* RT_SHAPE_KIND_MASK | RT_SHAPE_SHADOW | RT_SHAPE_CLOSED */
+  uint32_t xform;      /* index into xforms (0 = identity) */
+  uint32_t material;   /* index into materials */
+  int32_t parent;      /* node index of the owning group, -1 if none (src/shapes.rs:248-258) */
+  uint32_t vclass;     /* value class: equal <=> reference `Shape == Shape` (parent ignored) */
+  uint32_t prim;       /* (smooth) triangle: index into tri_geom / tri_normals */
+  float mn, mx;        /* cylinder/cone min,max (src/shapes/cylinder.rs:22-23) */
+} RtShape;
+
+/* Triangle edges (src/shapes/triangle.rs:32-48): p1, e1 = p2-p1, e2 = p3-p1. 48 B, 16-aligned. */
+typedef struct {
+  float p1[3], pad0;
+  float e1[3], pad1;
+  float e2[3], pad2;
+} RtTriGeom;
+/* Flat triangle: n1 = precomputed normal (triangle.rs:35); smooth: n1,n2,n3 (smooth_triangle.rs:24-26). */
+typedef struct {
+  float n1[3], pad0;
+  float n2[3], pad1;
+  float n3[3], pad2;
+} RtTriNormals;
+
+#define RT_NODE_ALL_TRIS 0x1u /* every shape of the node is an identity-transform (smooth) triangle */
+#define RT_NODE_PRUNABLE 0x2u /* the copied box really encloses the subtree: distance pruning allowed */
+/* One group (64 B), depth-first order. Replaces GroupData (src/groups.rs:20-26). */
+typedef struct {
+  float bmin[3];
+  uint32_t xform; /* 0 = identity */
+  float bmax[3];
+  uint32_t flags;
+  uint32_t first_shape, n_shapes; /* this group's own shapes: shapes[first_shape .. +n_shapes) */
+  uint32_t skip;                  /* index of the first node after this subtree */
+  int32_t parent;                 /* parent node or -1 */
+  uint32_t first_tri;             /* prim index of shapes[first_shape] when RT_NODE_ALL_TRIS */
+  int32_t next_xf;                /* nearest node at-or-above this one with a non-identity transform, -1 none */
+  uint32_t idrun;                 /* number of consecutive identity-transform nodes from here upwards */
+  uint32_t n_children;
+} RtNode;
+
+/* csg ops — src/csg.rs:110-114 */
+enum { RT_CSG_UNION = 0, RT_CSG_INTERSECT = 1, RT_CSG_DIFFERENCE = 2 };
+#define RT_CSG_LEFT_IS_SHAPE 0x1u
+#define RT_CSG_RIGHT_IS_SHAPE 0x2u
+/* One Csg node (48 B), post-order within its tree (children before parents). src/csg.rs:7-11. */
+typedef struct {
+  float bmin[3];
+  uint32_t op;
+  float bmax[3];
+  uint32_t flags;
+  int32_t left, right;       /* shape index (shapes[]) or csg node index, per flags */
+  uint32_t left_lo, left_hi; /* shape-index range of the leaves under `left` (Csg::includes, src/csg.rs:74-85) */
+} RtCsgNode;
+/* A top-level Csg of the world: csg_nodes[first .. first+count), root = last. */
+typedef struct {
+  uint32_t first, count;
+} RtCsgRoot;
+
+/* Material (src/materials.rs:6-33), 48 B. pattern = -1 for None. */
+typedef struct {
+  float color[3];
+  float ambient;
+  float diffuse, specular, shininess, reflective;
+  float transparency, refractive_index;
+  int32_t pattern;
+  uint32_t pad;
+} RtMaterial;
+
+enum { RT_PAT_STRIPED = 0, RT_PAT_GRADIENT, RT_PAT_RING, RT_PAT_CHECKER, RT_PAT_XYZ_RGB, RT_PAT_TEXTURE_MAP, RT_PAT_CUBE_MAP };
+enum { RT_UVMAP_SPHERICAL = 0, RT_UVMAP_PLANAR, RT_UVMAP_CYLINDRICAL };
+/* Pattern (src/patterns.rs:25-33), 80 B. uv[]: texture map uses uv[0]; cube map uses
+ * left,front,right,back,up,down (src/patterns/cube_map.rs:11-19). */
+typedef struct {
+  uint32_t kind;
+  uint32_t xform; /* inverse of the pattern transform, index into xforms */
+  uint32_t uv_mapping;
+  uint32_t pad;
+  float a[3], pad_a;
+  float b[3], pad_b;
+  int32_t uv[6];
+  uint32_t pad2[2];
+} RtPattern;
+
+enum { RT_UV_CHECKER = 0, RT_UV_ALIGN_CHECK, RT_UV_IMAGE };
+/* UvPattern (src/patterns/uv_pattern.rs:8-12), 80 B. */
+typedef struct {
+  uint32_t kind;
+  float width, height; /* checker */
+  int32_t image;       /* index into images */
+  float c[5][3];       /* checker: a,b ; align-check: main,ul,ur,bl,br */
+  uint32_t pad;
+} RtUvPattern;
+/* Canvas used as a texture (src/patterns/uv_pattern.rs:109-132): texels[offset ..] w*h*3 f32 */
+typedef struct {
+  uint32_t width, height;
+  uint64_t offset; /* in floats into `texels` */
+} RtImage;
+
+enum { RT_LIGHT_POINT = 0, RT_LIGHT_AREA = 1 };
+/* Light (src/lights.rs:36-40, :65-74), 96 B. uvec/vvec are already divided by the step counts. */
+typedef struct {
+  uint32_t kind;
+  uint32_t usteps, vsteps;
+  uint32_t pad;
+  float intensity[3], pad_i;
+  float position[3], pad_p;
+  float corner[3], pad_c;
+  float uvec[3], pad_u;
+  float vvec[3], pad_v;
+} RtLight;
+
+/* The flattened World (src/world.rs:12-18). */
+typedef struct {
+  uint32_t abi_version;
+  uint32_t recursion_limit; /* World::recursion_limit (src/world.rs:17, default 4) */
+  uint32_t n_xforms, n_shapes, n_tris, n_nodes, n_csg_nodes, n_csg_roots;
+  uint32_t n_materials, n_patterns, n_uvpatterns, n_images, n_lights;
+  uint32_t n_loose_shapes; /* trailing shapes[] entries that sit directly in World::shapes */
+  uint64_t n_texels;       /* floats */
+  const RtXform* xforms;
+  const RtShape* shapes;
+  const RtTriGeom* tri_geom;
+  const RtTriNormals* tri_normals;
+  const RtNode* nodes;
+  const RtCsgNode* csg_nodes;
+  const RtCsgRoot* csg_roots;
+  const RtMaterial* materials;
+  const RtPattern* patterns;
+  const RtUvPattern* uvpatterns;
+  const RtImage* images;
+  const float* texels;
+  const RtLight* lights;
+} RtScene;
+
+/* Camera (src/camera.rs:7-16): derived values are computed by the host exactly as
+ * Camera::new does (tanf on the host libm, src/camera.rs:19-38). */
+typedef struct {
+  uint32_t hsize, vsize;
+  float pixel_size, half_width, half_height;
+  float inv_transform[12]; /* rows 0..2 of transform.inverse() (src/camera.rs:58) */
+} RtCamera;
+
+enum { RT_JITTER_CONST = 0, RT_JITTER_COUNTER = 1 };
+typedef struct {
+  uint32_t jitter_mode; /* area-light jitter source (src/lights.rs:105-121), see DESIGN.md */
+  float jitter_value;
+  uint64_t seed;
+  /* interleaved scanline tiles (multi-GPU): this call renders the rows r with
+   * (r / tile_h) % n_parts == part, compacted in order.  n_parts = 1 renders everything. */
+  uint32_t tile_h, n_parts, part;
+  uint32_t flags; /* RT_RENDER_* */
+} RtRenderOptions;
+#define RT_RENDER_NO_PRUNE 0x1u /* visit every node the reference visits (no distance pruning) */
+
+/* Optional per-pixel side outputs of the PRIMARY ray, same compaction as the image. */
+typedef struct {
+  uint8_t* hit_mask;  /* 1 = hit */
+  int32_t* object_id; /* shape index (insertion rank) or -1 */
+  float* hit_t;
+} RtAux;
+
+/* Ray counters (one ray = one World::intersect-equivalent query) and timings. */
+typedef struct {
+  uint64_t primary, shadow, reflect, refract;
+  uint64_t overflow;   /* intersection-list overflows (must be 0 for a valid image) */
+  double kernel_ms;    /* device time of the render kernel(s), HIP events on the render stream */
+  double total_ms;     /* wall time of the call */
+} RtStats;
+
+typedef struct RtContext RtContext;         /* one GPU */
+typedef struct RtDeviceScene RtDeviceScene; /* a scene resident in that GPU's HBM */
+
+uint32_t rt_abi_version(void);
+/* device = HIP device ordinal. */
+int rt_context_create(int device, RtContext** out);
+void rt_context_destroy(RtContext*);
+const char* rt_last_error(const RtContext*);
+
+/* Upload a flattened world; validates limits (RT_E_SCENE). */
+int rt_scene_create(RtContext*, const RtScene*, RtDeviceScene** out);
+void rt_scene_destroy(RtContext*, RtDeviceScene*);
+
+/* Number of rows a (camera, options) pair renders on this part (for buffer sizing). */
+uint32_t rt_part_rows(const RtCamera*, const RtRenderOptions*);
+
+/* Camera::render (src/camera.rs:66-84): writes rows*hsize*3 f32 (row-major, unclamped) to HOST memory. */
+int rt_render(RtContext*, const RtDeviceScene*, const RtCamera*, const RtRenderOptions*, float* out_rgb,
+              RtAux* aux /* host pointers, may be NULL */, RtStats* stats /* may be NULL */);
+
+/* Same, but out_rgb / aux are DEVICE pointers on the context's GPU and nothing is copied back;
+ * `stream` is a hipStream_t (NULL = the context's own stream). The call is asynchronous unless
+ * stats != NULL (then it synchronises the stream to read the counters and event times). */
+int rt_render_device(RtContext*, const RtDeviceScene*, const RtCamera*, const RtRenderOptions*, float* d_out_rgb,
+                     RtAux* d_aux, void* stream, RtStats* stats);
+
+/* World::color_at(ray, remaining) (src/world.rs:91-99) and Intersections::hit()
+ * (src/intersections.rs:94-96) for n caller-supplied rays (host pointers): origins/directions
+ * n*3, out_rgb n*3, hit_t n (NaN on miss), hit_id n (-1 on miss), hit_uv n*2; outputs may be NULL. */
+int rt_color_at(RtContext*, const RtDeviceScene*, const RtRenderOptions*, const float* origins,
+                const float* directions, uint32_t n, uint32_t remaining, float* out_rgb, float* hit_t,
+                int32_t* hit_id, float* hit_uv, RtStats* stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_ABI_H */

@@ -1,0 +1,1214 @@
+// rt_host.cpp — librt_host.so: host side of the MI355X render path.
+//
+// Mirrors the reference's World-building interface (include/rt_builder.h, prefix rth_) in C++
+// because the reference is compiled code and there is no Rust toolchain here, and FLATTENS the
+// world into the device scene of include/rt_abi.h.  Rendering itself only happens in
+// librt_hip.so (HIP kernels); there is no CPU render path in this library.
+//
+// Host arithmetic that decides device inputs is restated exactly (f32, reference op order):
+//   * Matrix<4,4>::inverse by cofactor expansion (src/matrices.rs:146-198);
+//   * Transform op composition `op * acc` (src/transformations.rs:60-92), view_transform (:122-134);
+//   * BoundingBox add/transform/split/contains (src/bounds.rs:36-153);
+//   * Group::make_bounds with its null-parent quirk, partition and divide (src/groups.rs:166-299);
+//   * Camera::new (src/camera.rs:19-38), Triangle::new (src/shapes/triangle.rs:32-48).
+// Build: g++ -O2 -std=c++17 -ffp-contract=off -fno-fast-math -fPIC -shared (see __graft_entry__).
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <map>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#define RTB_PREFIX(name) rth_##name
+#include "../../../include/rt_abi.h"
+#include "../../../include/rt_builder.h"
+
+namespace {
+
+constexpr float kInf = std::numeric_limits<float>::infinity();
+
+// ---------------------------------------------------------------------------------------
+// 4x4 matrices, row-major flat storage
+// ---------------------------------------------------------------------------------------
+struct M4 {
+  float a[16];
+  float& at(int r, int c) { return a[4 * r + c]; }
+  float at(int r, int c) const { return a[4 * r + c]; }
+};
+M4 m4_identity() {
+  M4 m{};
+  m.a[0] = m.a[5] = m.a[10] = m.a[15] = 1.f;
+  return m;
+}
+bool m4_is_identity(const M4& m) {
+  M4 id = m4_identity();
+  for (int i = 0; i < 16; i++)
+    if (!(m.a[i] == id.a[i])) return false;
+  return true;
+}
+// src/matrices.rs:68-80: each entry is the k-ordered sum starting from 0.
+M4 m4_mul(const M4& x, const M4& y) {
+  M4 r;
+  for (int i = 0; i < 4; i++)
+    for (int j = 0; j < 4; j++) {
+      float s = 0.f;
+      for (int k = 0; k < 4; k++) s += x.at(i, k) * y.at(k, j);
+      r.at(i, j) = s;
+    }
+  return r;
+}
+// Determinant of the n x n matrix obtained from `m` (stride 4) by keeping rows[]/cols[]:
+// Laplace expansion along the first kept row, exactly as the reference nests
+// Matrix<4,4> -> Matrix<3,3> -> Matrix<2,2> (src/matrices.rs:100-183).
+float minor_det(const M4& m, const int* rows, const int* cols, int n) {
+  if (n == 2) return m.at(rows[0], cols[0]) * m.at(rows[1], cols[1]) - m.at(rows[1], cols[0]) * m.at(rows[0], cols[1]);
+  float det = 0.f;
+  int sub_cols[3];
+  for (int j = 0; j < n; j++) {
+    int w = 0;
+    for (int c = 0; c < n; c++)
+      if (c != j) sub_cols[w++] = cols[c];
+    float minor = minor_det(m, rows + 1, sub_cols, n - 1);
+    float cof = (j % 2 == 0) ? minor : -minor;
+    det += m.at(rows[0], cols[j]) * cof;
+  }
+  return det;
+}
+float m4_cofactor(const M4& m, int row, int col) {  // src/matrices.rs:147-175
+  int rows[3], cols[3];
+  for (int i = 0, w = 0; i < 4; i++)
+    if (i != row) rows[w++] = i;
+  for (int j = 0, w = 0; j < 4; j++)
+    if (j != col) cols[w++] = j;
+  float minor = minor_det(m, rows, cols, 3);
+  return ((row + col) % 2 == 0) ? minor : -minor;
+}
+bool m4_inverse(const M4& m, M4* out) {  // src/matrices.rs:177-197
+  float det = 0.f;
+  for (int j = 0; j < 4; j++) det += m.at(0, j) * m4_cofactor(m, 0, j);
+  if (det == 0.f) return false;
+  for (int i = 0; i < 4; i++)
+    for (int j = 0; j < 4; j++) out->at(j, i) = m4_cofactor(m, i, j) / det;
+  return true;
+}
+struct P3 {
+  float x, y, z;
+};
+// Matrix * Point (src/matrices.rs:200-227): rows 0..2, w = 1.
+P3 m4_point(const M4& m, P3 p) {
+  float v[4] = {p.x, p.y, p.z, 1.f};
+  float r[3];
+  for (int i = 0; i < 3; i++) {
+    float s = 0.f;
+    for (int k = 0; k < 4; k++) s += m.at(i, k) * v[k];
+    r[i] = s;
+  }
+  return P3{r[0], r[1], r[2]};
+}
+M4 op_matrix(const RtbXfOp& o) {  // src/transformations.rs:6-58
+  M4 m = m4_identity();
+  switch (o.op) {
+    case RTB_XF_TRANSLATE:
+      m.at(0, 3) = o.a[0];
+      m.at(1, 3) = o.a[1];
+      m.at(2, 3) = o.a[2];
+      break;
+    case RTB_XF_SCALE:
+      m.at(0, 0) = o.a[0];
+      m.at(1, 1) = o.a[1];
+      m.at(2, 2) = o.a[2];
+      break;
+    case RTB_XF_ROTATE_X:
+      m.at(1, 1) = cosf(o.a[0]);
+      m.at(1, 2) = -sinf(o.a[0]);
+      m.at(2, 1) = sinf(o.a[0]);
+      m.at(2, 2) = cosf(o.a[0]);
+      break;
+    case RTB_XF_ROTATE_Y:
+      m.at(0, 0) = cosf(o.a[0]);
+      m.at(0, 2) = sinf(o.a[0]);
+      m.at(2, 0) = -sinf(o.a[0]);
+      m.at(2, 2) = cosf(o.a[0]);
+      break;
+    case RTB_XF_ROTATE_Z:
+      m.at(0, 0) = cosf(o.a[0]);
+      m.at(0, 1) = -sinf(o.a[0]);
+      m.at(1, 0) = sinf(o.a[0]);
+      m.at(1, 1) = cosf(o.a[0]);
+      break;
+    case RTB_XF_SHEAR:
+      m.at(0, 1) = o.a[0];
+      m.at(0, 2) = o.a[1];
+      m.at(1, 0) = o.a[2];
+      m.at(1, 2) = o.a[3];
+      m.at(2, 0) = o.a[4];
+      m.at(2, 1) = o.a[5];
+      break;
+    default: std::memcpy(m.a, o.m, sizeof(m.a)); break;
+  }
+  return m;
+}
+M4 compose(const RtbXfOp* ops, int n) {  // src/transformations.rs:60-92
+  M4 acc = m4_identity();
+  for (int i = 0; i < n; i++) acc = m4_mul(op_matrix(ops[i]), acc);
+  return acc;
+}
+P3 sub3(P3 a, P3 b) { return P3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+P3 cross3(P3 a, P3 b) { return P3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+P3 normalize3(P3 a) {  // src/tuples.rs:232-238 with w = 0
+  float mag = std::sqrt(a.x * a.x + a.y * a.y + a.z * a.z + 0.f * 0.f);
+  return P3{a.x / mag, a.y / mag, a.z / mag};
+}
+M4 view_matrix(P3 from, P3 to, P3 up) {  // src/transformations.rs:122-134
+  P3 forward = normalize3(sub3(to, from));
+  P3 upn = normalize3(up);
+  P3 left = cross3(forward, upn);
+  P3 true_up = cross3(left, forward);
+  M4 o{};
+  o.at(0, 0) = left.x, o.at(0, 1) = left.y, o.at(0, 2) = left.z;
+  o.at(1, 0) = true_up.x, o.at(1, 1) = true_up.y, o.at(1, 2) = true_up.z;
+  o.at(2, 0) = -forward.x, o.at(2, 1) = -forward.y, o.at(2, 2) = -forward.z;
+  o.at(3, 3) = 1.f;
+  RtbXfOp t{};
+  t.op = RTB_XF_TRANSLATE;
+  t.a[0] = -from.x, t.a[1] = -from.y, t.a[2] = -from.z;
+  return m4_mul(o, op_matrix(t));
+}
+
+// ---------------------------------------------------------------------------------------
+// Boxes (src/bounds.rs)
+// ---------------------------------------------------------------------------------------
+struct Box {
+  P3 lo{kInf, kInf, kInf}, hi{-kInf, -kInf, -kInf};
+};
+void box_add(Box& b, P3 p) {  // :55-74
+  if (p.x < b.lo.x) b.lo.x = p.x;
+  if (p.y < b.lo.y) b.lo.y = p.y;
+  if (p.z < b.lo.z) b.lo.z = p.z;
+  if (p.x > b.hi.x) b.hi.x = p.x;
+  if (p.y > b.hi.y) b.hi.y = p.y;
+  if (p.z > b.hi.z) b.hi.z = p.z;
+}
+void box_merge(Box& b, const Box& o) {  // :76-79
+  box_add(b, o.lo);
+  box_add(b, o.hi);
+}
+Box box_transform(const Box& b, const M4& t) {  // :36-53, corner order as in the reference
+  Box r;
+  const float xs[2] = {b.lo.x, b.hi.x}, ys[2] = {b.lo.y, b.hi.y}, zs[2] = {b.lo.z, b.hi.z};
+  for (int i = 0; i < 2; i++)
+    for (int j = 0; j < 2; j++)
+      for (int k = 0; k < 2; k++) box_add(r, m4_point(t, P3{xs[i], ys[j], zs[k]}));
+  return r;
+}
+bool box_has_point(const Box& b, P3 p) {  // :81-85
+  return b.lo.x <= p.x && p.x <= b.hi.x && b.lo.y <= p.y && p.y <= b.hi.y && b.lo.z <= p.z && p.z <= b.hi.z;
+}
+bool box_has_box(const Box& b, const Box& o) { return box_has_point(b, o.lo) && box_has_point(b, o.hi); }  // :87-89
+inline bool tot_gt(float a, float b) { return (a > b) || (std::isnan(a) && !std::isnan(b)); }
+inline bool tot_eq(float a, float b) { return std::isnan(a) ? std::isnan(b) : a == b; }
+void box_split(const Box& b, Box* l, Box* r) {  // :125-153
+  float d[3] = {std::fabs(b.hi.x - b.lo.x), std::fabs(b.hi.y - b.lo.y), std::fabs(b.hi.z - b.lo.z)};
+  float g = tot_gt(d[0], d[1]) ? d[0] : d[1];
+  g = tot_gt(g, d[2]) ? g : d[2];
+  P3 mid_lo = b.lo, mid_hi = b.hi;
+  if (tot_eq(g, d[0])) {
+    mid_hi.x = b.lo.x + d[0] / 2.f;
+    mid_lo.x = b.lo.x + d[0] / 2.f;
+  } else if (tot_eq(g, d[1])) {
+    mid_hi.y = b.lo.y + d[1] / 2.f;
+    mid_lo.y = b.lo.y + d[1] / 2.f;
+  } else {
+    mid_hi.z = b.lo.z + d[2] / 2.f;
+    mid_lo.z = b.lo.z + d[2] / 2.f;
+  }
+  l->lo = b.lo;
+  l->hi = mid_hi;
+  r->lo = mid_lo;
+  r->hi = b.hi;
+}
+
+// ---------------------------------------------------------------------------------------
+// World model (index based arenas)
+// ---------------------------------------------------------------------------------------
+struct HUv {
+  int kind = 0;
+  float width = 0, height = 0;
+  float c[5][3] = {};
+  int image = -1;
+};
+struct HImage {
+  uint32_t w = 0, h = 0;
+  std::vector<float> rgb;
+};
+struct HPattern {
+  int kind = 0;
+  float a[3] = {}, b[3] = {};
+  M4 xf, inv;
+  int uv_mapping = 0;
+  int uv[6] = {-1, -1, -1, -1, -1, -1};
+};
+struct HTri {
+  P3 p1, p2, p3, e1, e2;
+  P3 n1, n2, n3;  // flat: n1 = normal
+};
+struct HShape {
+  uint8_t kind = RTB_SPHERE;
+  bool shadow = true, closed = false;
+  float mn = -kInf, mx = kInf;
+  M4 xf = m4_identity(), inv = m4_identity();
+  bool identity = true;
+  RtbMaterial mat{};
+  int tri = -1;
+  int parent = -1;
+  Box psb;  // parent_space_bounds(), constant for the life of the shape
+};
+struct HGroup {
+  M4 xf = m4_identity(), inv = m4_identity();
+  std::vector<uint32_t> shapes;
+  std::vector<int> children;
+  int parent = -1;
+  bool cached = false;
+  Box bounds;
+};
+struct HCsg {
+  int op = 0;
+  int lkind = 0, l = -1, rkind = 0, r = -1;
+};
+struct HLight {
+  RtLight l{};
+};
+
+RtbMaterial default_material() {  // src/materials.rs:19-33
+  RtbMaterial m{};
+  m.color[0] = m.color[1] = m.color[2] = 1.f;
+  m.ambient = 0.1f;
+  m.diffuse = 0.9f;
+  m.specular = 0.9f;
+  m.shininess = 200.f;
+  m.reflective = 0.f;
+  m.transparency = 0.f;
+  m.refractive_index = 1.f;
+  m.pattern = -1;
+  return m;
+}
+
+// Keys for value classes: raw bits with -0 folded onto +0; NaN poisons the key.
+struct KeyBuilder {
+  std::string bytes;
+  bool nan = false;
+  void f(float v) {
+    if (std::isnan(v)) nan = true;
+    if (v == 0.f) v = 0.f;
+    bytes.append(reinterpret_cast<const char*>(&v), 4);
+  }
+  void fs(const float* v, int n) {
+    for (int i = 0; i < n; i++) f(v[i]);
+  }
+  void u(uint32_t v) { bytes.append(reinterpret_cast<const char*>(&v), 4); }
+};
+struct ClassTable {
+  std::unordered_map<std::string, uint32_t> ids;
+  uint32_t next = 0;
+  uint32_t get(const KeyBuilder& k) {
+    if (k.nan) return RT_VCLASS_NEVER;
+    auto it = ids.find(k.bytes);
+    if (it != ids.end()) return it->second;
+    ids.emplace(k.bytes, next);
+    return next++;
+  }
+};
+
+struct Flat {
+  std::vector<RtXform> xforms;
+  std::vector<RtShape> shapes;
+  std::vector<RtTriGeom> tri_geom;
+  std::vector<RtTriNormals> tri_normals;
+  std::vector<RtNode> nodes;
+  std::vector<RtCsgNode> csg_nodes;
+  std::vector<RtCsgRoot> csg_roots;
+  std::vector<RtMaterial> materials;
+  std::vector<RtPattern> patterns;
+  std::vector<RtUvPattern> uvpatterns;
+  std::vector<RtImage> images;
+  std::vector<float> texels;
+  std::vector<RtLight> lights;
+  RtScene view{};
+};
+
+}  // namespace
+
+struct RtbWorld {
+  std::vector<HShape> shapes;  // arena: detached shapes and every placed copy
+  std::vector<HTri> tris;
+  std::vector<HGroup> groups;
+  std::vector<HCsg> csgs;
+  std::vector<HUv> uvs;
+  std::vector<HImage> images;
+  std::vector<HPattern> patterns;
+  std::vector<HLight> lights;
+  std::vector<uint32_t> world_shapes;
+  std::vector<int> world_groups;
+  std::vector<int> world_csgs;
+  int recursion_limit = 4;
+  std::string error;
+
+  bool dirty = true;
+  std::unique_ptr<Flat> flat;
+  RtContext* ctx = nullptr;
+  RtDeviceScene* dscene = nullptr;
+  int device = 0;
+
+  ~RtbWorld() { drop_device(); }
+  void drop_device() {
+    if (dscene) rt_scene_destroy(ctx, dscene);
+    dscene = nullptr;
+    if (ctx) rt_context_destroy(ctx);
+    ctx = nullptr;
+  }
+  void touch() {
+    dirty = true;
+    if (dscene) {
+      rt_scene_destroy(ctx, dscene);
+      dscene = nullptr;
+    }
+  }
+
+  // ---- shapes ---------------------------------------------------------------------------
+  Box local_bounds(const HShape& s) const {
+    Box b;
+    switch (s.kind) {
+      case RTB_SPHERE:
+      case RTB_CUBE: b.lo = P3{-1.f, -1.f, -1.f}, b.hi = P3{1.f, 1.f, 1.f}; break;     // sphere.rs:86-90, cube.rs:135-139
+      case RTB_PLANE: b.lo = P3{-kInf, 0.f, -kInf}, b.hi = P3{kInf, 0.f, kInf}; break;  // plane.rs:79-83
+      case RTB_CYLINDER: b.lo = P3{-1.f, s.mn, -1.f}, b.hi = P3{1.f, s.mx, 1.f}; break;  // cylinder.rs:169-173
+      case RTB_CONE: {                                                                    // cone.rs:182-193
+        float a = std::fabs(s.mn), c = std::fabs(s.mx);
+        float lim = (std::isinf(a) || std::isinf(c)) ? kInf : (tot_gt(a, c) ? a : c);
+        b.lo = P3{-lim, s.mn, -lim}, b.hi = P3{lim, s.mx, lim};
+        break;
+      }
+      default: {  // triangle.rs:117-123
+        const HTri& t = tris[s.tri];
+        box_add(b, t.p1);
+        box_add(b, t.p2);
+        box_add(b, t.p3);
+      }
+    }
+    return b;
+  }
+  uint32_t clone_shape(uint32_t id) {
+    shapes.push_back(shapes[id]);
+    return (uint32_t)shapes.size() - 1;
+  }
+
+  // ---- groups (src/groups.rs) -----------------------------------------------------------
+  int group_len(int g) const { return (int)(groups[g].shapes.size() + groups[g].children.size()); }
+  Box group_bounds(int g) const {  // :166-174
+    if (groups[g].cached) return groups[g].bounds;
+    return make_bounds(g);
+  }
+  Box make_bounds(int g) const {  // :176-188
+    const HGroup& gr = groups[g];
+    Box bb;
+    for (uint32_t s : gr.shapes) box_merge(bb, shapes[s].psb);
+    for (int c : gr.children) {
+      if (gr.parent < 0) bb = box_transform(bb, gr.xf);  // the reference's root-with-children quirk
+      box_merge(bb, group_bounds(c));
+    }
+    return bb;
+  }
+  void attach_child(int g, int c) {  // :64-72
+    groups[g].children.push_back(c);
+    groups[c].parent = g;
+  }
+  int new_group() {
+    groups.emplace_back();
+    return (int)groups.size() - 1;
+  }
+  void partition(int g, int* lo_out, int* hi_out) {  // :198-282
+    Box lb, rb;
+    box_split(group_bounds(g), &lb, &rb);
+    std::vector<uint32_t> all;
+    all.swap(groups[g].shapes);
+    std::vector<uint32_t> ls, rs, keep;
+    for (uint32_t s : all) {
+      if (box_has_box(lb, shapes[s].psb))
+        ls.push_back(s);
+      else if (box_has_box(rb, shapes[s].psb))
+        rs.push_back(s);
+      else
+        keep.push_back(s);
+    }
+    groups[g].shapes = std::move(keep);
+    std::vector<int> kids;
+    kids.swap(groups[g].children);
+    std::vector<int> lk, rk, keepk;
+    for (int c : kids) {
+      Box cb = group_bounds(c);
+      if (box_has_box(lb, cb))
+        lk.push_back(c);
+      else if (box_has_box(rb, cb))
+        rk.push_back(c);
+      else
+        keepk.push_back(c);
+    }
+    groups[g].children = std::move(keepk);
+    int L = new_group();
+    groups[L].shapes = std::move(ls);
+    groups[L].children = lk;
+    for (uint32_t s : groups[L].shapes) shapes[s].parent = L;
+    for (int c : lk) groups[c].parent = L;
+    int R = new_group();
+    groups[R].shapes = std::move(rs);
+    groups[R].children = rk;
+    for (uint32_t s : groups[R].shapes) shapes[s].parent = R;
+    for (int c : rk) groups[c].parent = R;
+    *lo_out = L;
+    *hi_out = R;
+  }
+  void divide(int g, int threshold) {  // :284-299
+    if (threshold <= group_len(g)) {
+      int L, R;
+      partition(g, &L, &R);
+      if (group_len(L) != 0) attach_child(g, L);
+      if (group_len(R) != 0) attach_child(g, R);
+    }
+    std::vector<int> kids = groups[g].children;
+    for (int c : kids) divide(c, threshold);
+  }
+
+  // ---- flatten (World -> RtScene) -----------------------------------------------------
+  bool flatten();
+};
+
+namespace {
+
+int fail(RtbWorld* w, const std::string& msg, int code = -1) {
+  w->error = msg;
+  return code;
+}
+
+struct Flattener {
+  RtbWorld& w;
+  Flat& f;
+  std::map<std::vector<uint32_t>, uint32_t> xform_ids;
+  ClassTable uv_classes, pattern_classes, material_classes, shape_classes;
+  std::unordered_map<uint32_t, uint32_t> material_slot;  // material class -> materials[] index
+  std::vector<int> uv_class_of, pattern_class_of;
+  std::vector<Box> true_box;  // per node, conservative box of the subtree in the node's space
+
+  Flattener(RtbWorld& w_, Flat& f_) : w(w_), f(f_) {}
+
+  uint32_t xform_index(const M4& inv, bool identity) {
+    if (identity) return 0;
+    std::vector<uint32_t> key(12);
+    std::memcpy(key.data(), inv.a, 48);
+    auto it = xform_ids.find(key);
+    if (it != xform_ids.end()) return it->second;
+    RtXform x;
+    std::memcpy(x.m, inv.a, 48);
+    f.xforms.push_back(x);
+    uint32_t id = (uint32_t)f.xforms.size() - 1;
+    xform_ids.emplace(std::move(key), id);
+    return id;
+  }
+
+  void tables() {
+    RtXform id{};
+    id.m[0] = id.m[5] = id.m[10] = 1.f;
+    f.xforms.push_back(id);
+    // images
+    for (auto& im : w.images) {
+      RtImage r{im.w, im.h, (uint64_t)f.texels.size()};
+      f.texels.insert(f.texels.end(), im.rgb.begin(), im.rgb.end());
+      f.images.push_back(r);
+    }
+    // uv patterns (value classes feed pattern equality)
+    for (auto& u : w.uvs) {
+      RtUvPattern r{};
+      r.kind = u.kind;
+      r.width = u.width;
+      r.height = u.height;
+      r.image = u.image;
+      std::memcpy(r.c, u.c, sizeof(r.c));
+      f.uvpatterns.push_back(r);
+      KeyBuilder k;
+      k.u(u.kind);
+      if (u.kind == 0) {
+        k.f(u.width), k.f(u.height), k.fs(u.c[0], 6);
+      } else if (u.kind == 1) {
+        k.fs(u.c[0], 15);
+      } else {
+        k.u((uint32_t)u.image);
+      }
+      uv_class_of.push_back((int)uv_classes.get(k));
+    }
+    for (auto& p : w.patterns) {
+      RtPattern r{};
+      r.kind = p.kind;
+      r.xform = xform_index(p.inv, m4_is_identity(p.xf));
+      r.uv_mapping = p.uv_mapping;
+      std::memcpy(r.a, p.a, 12);
+      std::memcpy(r.b, p.b, 12);
+      for (int i = 0; i < 6; i++) r.uv[i] = p.uv[i];
+      f.patterns.push_back(r);
+      KeyBuilder k;
+      k.u(p.kind);
+      k.fs(p.xf.a, 16);
+      if (p.kind == RTB_PAT_TEXTURE_MAP) {
+        k.u(p.uv_mapping);
+        k.u((uint32_t)uv_class_of[p.uv[0]]);
+        if ((uint32_t)uv_class_of[p.uv[0]] == RT_VCLASS_NEVER) k.nan = true;
+      } else if (p.kind == RTB_PAT_CUBE_MAP) {
+        for (int i = 0; i < 6; i++) {
+          k.u((uint32_t)uv_class_of[p.uv[i]]);
+          if ((uint32_t)uv_class_of[p.uv[i]] == RT_VCLASS_NEVER) k.nan = true;
+        }
+      } else if (p.kind != RTB_PAT_XYZ_RGB) {
+        k.fs(p.a, 3), k.fs(p.b, 3);
+      }
+      pattern_class_of.push_back((int)pattern_classes.get(k));
+    }
+  }
+
+  // material -> (materials[] index, value class)
+  void material(const RtbMaterial& m, uint32_t* index, uint32_t* vclass) {
+    KeyBuilder k;
+    k.fs(m.color, 3);
+    k.f(m.ambient), k.f(m.diffuse), k.f(m.specular), k.f(m.shininess), k.f(m.reflective), k.f(m.transparency),
+        k.f(m.refractive_index);
+    if (m.pattern >= 0) {
+      uint32_t pc = (uint32_t)pattern_class_of[m.pattern];
+      if (pc == RT_VCLASS_NEVER) k.nan = true;
+      k.u(1), k.u(pc);
+    } else {
+      k.u(0), k.u(0);
+    }
+    uint32_t cls = material_classes.get(k);
+    *vclass = cls;
+    if (cls != RT_VCLASS_NEVER) {
+      auto it = material_slot.find(cls);
+      if (it != material_slot.end()) {
+        *index = it->second;
+        return;
+      }
+    }
+    RtMaterial r{};
+    std::memcpy(r.color, m.color, 12);
+    r.ambient = m.ambient, r.diffuse = m.diffuse, r.specular = m.specular, r.shininess = m.shininess;
+    r.reflective = m.reflective, r.transparency = m.transparency, r.refractive_index = m.refractive_index;
+    r.pattern = m.pattern;
+    f.materials.push_back(r);
+    *index = (uint32_t)f.materials.size() - 1;
+    if (cls != RT_VCLASS_NEVER) material_slot.emplace(cls, *index);
+  }
+
+  uint32_t emit_shape(uint32_t sid, int parent_node) {
+    const HShape& s = w.shapes[sid];
+    RtShape r{};
+    r.kind_flags = s.kind | (s.shadow ? RT_SHAPE_SHADOW : 0u) | (s.closed ? RT_SHAPE_CLOSED : 0u);
+    r.xform = xform_index(s.inv, s.identity);
+    uint32_t mclass;
+    material(s.mat, &r.material, &mclass);
+    r.parent = parent_node;
+    r.mn = s.mn;
+    r.mx = s.mx;
+    KeyBuilder k;
+    k.u(s.kind), k.fs(s.xf.a, 16), k.u(mclass), k.u(s.shadow ? 1 : 0);
+    if (mclass == RT_VCLASS_NEVER) k.nan = true;
+    if (s.kind == RTB_CYLINDER || s.kind == RTB_CONE) {
+      // -inf/+inf compare equal to themselves; keep their bits
+      k.f(s.mn), k.f(s.mx), k.u(s.closed ? 1 : 0);
+    } else if (s.kind >= RTB_TRIANGLE) {
+      const HTri& t = w.tris[s.tri];
+      RtTriGeom g{};
+      g.p1[0] = t.p1.x, g.p1[1] = t.p1.y, g.p1[2] = t.p1.z;
+      g.e1[0] = t.e1.x, g.e1[1] = t.e1.y, g.e1[2] = t.e1.z;
+      g.e2[0] = t.e2.x, g.e2[1] = t.e2.y, g.e2[2] = t.e2.z;
+      RtTriNormals n{};
+      n.n1[0] = t.n1.x, n.n1[1] = t.n1.y, n.n1[2] = t.n1.z;
+      n.n2[0] = t.n2.x, n.n2[1] = t.n2.y, n.n2[2] = t.n2.z;
+      n.n3[0] = t.n3.x, n.n3[1] = t.n3.y, n.n3[2] = t.n3.z;
+      r.prim = (uint32_t)f.tri_geom.size();
+      f.tri_geom.push_back(g);
+      f.tri_normals.push_back(n);
+      // Triangle == compares p1,p2,p3,e1,e2 and normal / n1..n3 (triangle.rs:14-27)
+      const P3* ps[5] = {&t.p1, &t.p2, &t.p3, &t.e1, &t.e2};
+      for (auto p : ps) k.f(p->x), k.f(p->y), k.f(p->z);
+      k.f(t.n1.x), k.f(t.n1.y), k.f(t.n1.z);
+      if (s.kind == RTB_SMOOTH_TRIANGLE) {
+        k.f(t.n2.x), k.f(t.n2.y), k.f(t.n2.z), k.f(t.n3.x), k.f(t.n3.y), k.f(t.n3.z);
+      }
+    }
+    r.vclass = shape_classes.get(k);
+    f.shapes.push_back(r);
+    return (uint32_t)f.shapes.size() - 1;
+  }
+
+  // csg: leaves in tie order (shape child before csg child, else left then right; csg.rs:32-46),
+  // nodes in post-order.  Returns the node index; *lo/*hi = leaf shape range of the subtree.
+  Box csg_bounds(int c) {  // csg.rs:87-105
+    const HCsg& n = w.csgs[c];
+    Box bb;
+    auto add = [&](int kind, int id) {
+      if (kind == RTB_CHILD_SHAPE)
+        box_merge(bb, w.shapes[id].psb);
+      else
+        box_merge(bb, csg_bounds(id));
+    };
+    if (n.lkind == RTB_CHILD_CSG && n.rkind == RTB_CHILD_SHAPE) {
+      add(n.rkind, n.r);
+      add(n.lkind, n.l);
+    } else {
+      add(n.lkind, n.l);
+      add(n.rkind, n.r);
+    }
+    return bb;
+  }
+  int emit_csg(int c, uint32_t* lo, uint32_t* hi) {
+    const HCsg n = w.csgs[c];
+    RtCsgNode r{};
+    r.op = n.op;
+    uint32_t llo = 0, lhi = 0, rlo = 0, rhi = 0;
+    auto child = [&](int kind, int id, int32_t* out, uint32_t* clo, uint32_t* chi, uint32_t flag) {
+      if (kind == RTB_CHILD_SHAPE) {
+        uint32_t s = emit_shape((uint32_t)id, -1);
+        *out = (int32_t)s;
+        *clo = s;
+        *chi = s + 1;
+        r.flags |= flag;
+      } else {
+        *out = emit_csg(id, clo, chi);
+      }
+    };
+    if (n.lkind == RTB_CHILD_CSG && n.rkind == RTB_CHILD_SHAPE) {
+      child(n.rkind, n.r, &r.right, &rlo, &rhi, RT_CSG_RIGHT_IS_SHAPE);
+      child(n.lkind, n.l, &r.left, &llo, &lhi, RT_CSG_LEFT_IS_SHAPE);
+    } else {
+      child(n.lkind, n.l, &r.left, &llo, &lhi, RT_CSG_LEFT_IS_SHAPE);
+      child(n.rkind, n.r, &r.right, &rlo, &rhi, RT_CSG_RIGHT_IS_SHAPE);
+    }
+    r.left_lo = llo;
+    r.left_hi = lhi;
+    Box bb = csg_bounds(c);
+    r.bmin[0] = bb.lo.x, r.bmin[1] = bb.lo.y, r.bmin[2] = bb.lo.z;
+    r.bmax[0] = bb.hi.x, r.bmax[1] = bb.hi.y, r.bmax[2] = bb.hi.z;
+    *lo = std::min(llo, rlo);
+    *hi = std::max(lhi, rhi);
+    f.csg_nodes.push_back(r);
+    return (int)f.csg_nodes.size() - 1;
+  }
+
+  // groups depth-first; returns the node index
+  uint32_t emit_group(int g, int parent_node, Box* bounds_out, Box* true_out) {
+    uint32_t idx = (uint32_t)f.nodes.size();
+    f.nodes.emplace_back();
+    true_box.emplace_back();
+    const HGroup& gr = w.groups[g];
+    bool identity = m4_is_identity(gr.xf);
+    uint32_t xf = xform_index(gr.inv, identity);
+    uint32_t first_shape = (uint32_t)f.shapes.size();
+    uint32_t first_tri = (uint32_t)f.tri_geom.size();
+    bool all_tris = !gr.shapes.empty();
+    Box tb;   // true (conservative) box
+    Box bb;   // the reference's make_bounds (groups.rs:176-188), recomputed with final parent state
+    for (uint32_t s : gr.shapes) {
+      const HShape& hs = w.shapes[s];
+      if (!(hs.kind >= RTB_TRIANGLE && hs.identity)) all_tris = false;
+      emit_shape(s, (int)idx);
+      box_merge(tb, hs.psb);
+      box_merge(bb, hs.psb);
+    }
+    uint32_t n_shapes = (uint32_t)gr.shapes.size();
+    {
+      RtNode& n = f.nodes[idx];
+      n.xform = xf;
+      n.first_shape = first_shape;
+      n.n_shapes = n_shapes;
+      n.parent = parent_node;
+      n.first_tri = first_tri;
+      n.n_children = (uint32_t)gr.children.size();
+      if (xf) {
+        n.next_xf = (int32_t)idx;
+        n.idrun = 0;
+      } else {
+        n.next_xf = parent_node >= 0 ? f.nodes[parent_node].next_xf : -1;
+        n.idrun = 1 + (parent_node >= 0 ? f.nodes[parent_node].idrun : 0);
+      }
+    }
+    for (int c : gr.children) {
+      Box cb, ctb;
+      emit_group(c, (int)idx, &cb, &ctb);
+      if (gr.parent < 0) bb = box_transform(bb, gr.xf);
+      box_merge(bb, cb);
+      // child's true box, expressed in this node's space
+      const HGroup& cg = w.groups[c];
+      if (m4_is_identity(cg.xf))
+        box_merge(tb, ctb);
+      else
+        box_merge(tb, box_transform(ctb, cg.xf));
+    }
+    if (gr.cached) bb = gr.bounds;  // cache_bounds() result taken at World-add time (scene.rs:197)
+    RtNode& n = f.nodes[idx];
+    n.bmin[0] = bb.lo.x, n.bmin[1] = bb.lo.y, n.bmin[2] = bb.lo.z;
+    n.bmax[0] = bb.hi.x, n.bmax[1] = bb.hi.y, n.bmax[2] = bb.hi.z;
+    n.skip = (uint32_t)f.nodes.size();
+    bool encloses = tb.lo.x >= bb.lo.x && tb.lo.y >= bb.lo.y && tb.lo.z >= bb.lo.z && tb.hi.x <= bb.hi.x &&
+                    tb.hi.y <= bb.hi.y && tb.hi.z <= bb.hi.z;  // false if any NaN
+    bool empty = tb.lo.x > tb.hi.x && tb.lo.y > tb.hi.y && tb.lo.z > tb.hi.z;
+    n.flags = (all_tris ? RT_NODE_ALL_TRIS : 0u) | ((encloses || empty) ? RT_NODE_PRUNABLE : 0u);
+    true_box[idx] = tb;
+    *bounds_out = bb;
+    *true_out = tb;
+    return idx;
+  }
+
+  void run() {
+    tables();
+    for (int c : w.world_csgs) {
+      uint32_t first = (uint32_t)f.csg_nodes.size();
+      uint32_t lo, hi;
+      emit_csg(c, &lo, &hi);
+      f.csg_roots.push_back(RtCsgRoot{first, (uint32_t)f.csg_nodes.size() - first});
+    }
+    for (int g : w.world_groups) {
+      Box b, t;
+      emit_group(g, -1, &b, &t);
+    }
+    uint32_t loose0 = (uint32_t)f.shapes.size();
+    for (uint32_t s : w.world_shapes) emit_shape(s, -1);
+    for (auto& l : w.lights) f.lights.push_back(l.l);
+    RtScene& v = f.view;
+    v = RtScene{};
+    v.abi_version = RT_ABI_VERSION;
+    v.recursion_limit = (uint32_t)w.recursion_limit;
+    v.n_xforms = (uint32_t)f.xforms.size();
+    v.n_shapes = (uint32_t)f.shapes.size();
+    v.n_tris = (uint32_t)f.tri_geom.size();
+    v.n_nodes = (uint32_t)f.nodes.size();
+    v.n_csg_nodes = (uint32_t)f.csg_nodes.size();
+    v.n_csg_roots = (uint32_t)f.csg_roots.size();
+    v.n_materials = (uint32_t)f.materials.size();
+    v.n_patterns = (uint32_t)f.patterns.size();
+    v.n_uvpatterns = (uint32_t)f.uvpatterns.size();
+    v.n_images = (uint32_t)f.images.size();
+    v.n_lights = (uint32_t)f.lights.size();
+    v.n_loose_shapes = (uint32_t)f.shapes.size() - loose0;
+    v.n_texels = f.texels.size();
+    v.xforms = f.xforms.data();
+    v.shapes = f.shapes.data();
+    v.tri_geom = f.tri_geom.data();
+    v.tri_normals = f.tri_normals.data();
+    v.nodes = f.nodes.data();
+    v.csg_nodes = f.csg_nodes.data();
+    v.csg_roots = f.csg_roots.data();
+    v.materials = f.materials.data();
+    v.patterns = f.patterns.data();
+    v.uvpatterns = f.uvpatterns.data();
+    v.images = f.images.data();
+    v.texels = f.texels.data();
+    v.lights = f.lights.data();
+  }
+};
+
+bool make_rt_camera(const RtbCamera* d, RtCamera* c) {  // src/camera.rs:19-43
+  c->hsize = d->hsize;
+  c->vsize = d->vsize;
+  float half_view = tanf(d->field_of_view / 2.f);
+  float aspect = (float)d->hsize / (float)d->vsize;
+  if (aspect >= 1.f) {
+    c->half_width = half_view;
+    c->half_height = half_view / aspect;
+  } else {
+    c->half_width = half_view * aspect;
+    c->half_height = half_view;
+  }
+  c->pixel_size = (c->half_width * 2.f) / (float)d->hsize;
+  M4 t = d->use_view ? view_matrix(P3{d->from[0], d->from[1], d->from[2]}, P3{d->to[0], d->to[1], d->to[2]},
+                                   P3{d->up[0], d->up[1], d->up[2]})
+                     : compose(d->ops, d->nops);
+  M4 inv;
+  if (!m4_inverse(t, &inv)) return false;
+  std::memcpy(c->inv_transform, inv.a, 48);
+  return true;
+}
+
+bool set_shape_transform(HShape& s, const RtbXfOp* ops, int nops) {
+  s.xf = compose(ops, nops);
+  s.identity = m4_is_identity(s.xf);
+  return m4_inverse(s.xf, &s.inv);
+}
+
+RtRenderOptions to_rt_options(const RtbRenderOptions* o) {
+  RtRenderOptions r{};
+  r.jitter_mode = (o && o->jitter_mode == RTB_JITTER_COUNTER) ? RT_JITTER_COUNTER : RT_JITTER_CONST;
+  r.jitter_value = o ? o->jitter_value : 0.5f;
+  r.seed = o ? o->seed : 0;
+  r.tile_h = 1;
+  r.n_parts = 1;
+  r.part = 0;
+  r.flags = 0;
+  return r;
+}
+
+}  // namespace
+
+bool RtbWorld::flatten() {
+  if (!dirty && flat) return true;
+  flat.reset(new Flat());
+  Flattener fl(*this, *flat);
+  fl.run();
+  dirty = false;
+  return true;
+}
+
+extern "C" {
+
+RtbWorld* rth_world_new(void) { return new RtbWorld(); }
+void rth_world_free(RtbWorld* w) { delete w; }
+const char* rth_last_error(const RtbWorld* w) { return w->error.c_str(); }
+
+int rth_uv_checker(RtbWorld* w, float width, float height, const float a[3], const float b[3]) {
+  HUv u;
+  u.kind = 0;
+  u.width = width;
+  u.height = height;
+  std::memcpy(u.c[0], a, 12);
+  std::memcpy(u.c[1], b, 12);
+  w->uvs.push_back(u);
+  return (int)w->uvs.size() - 1;
+}
+int rth_uv_align_check(RtbWorld* w, const float c[15]) {
+  HUv u;
+  u.kind = 1;
+  std::memcpy(u.c, c, 60);
+  w->uvs.push_back(u);
+  return (int)w->uvs.size() - 1;
+}
+int rth_uv_image(RtbWorld* w, uint32_t width, uint32_t height, const float* rgb) {
+  HImage im;
+  im.w = width;
+  im.h = height;
+  im.rgb.assign(rgb, rgb + (size_t)width * height * 3);
+  w->images.push_back(std::move(im));
+  HUv u;
+  u.kind = 2;
+  u.image = (int)w->images.size() - 1;
+  w->uvs.push_back(u);
+  return (int)w->uvs.size() - 1;
+}
+int rth_pattern_new(RtbWorld* w, int kind, const float colors[6], const RtbXfOp* ops, int nops, int uv_mapping,
+                    const int32_t* uvpats) {
+  HPattern p;
+  p.kind = kind;
+  if (colors) {
+    std::memcpy(p.a, colors, 12);
+    std::memcpy(p.b, colors + 3, 12);
+  }
+  p.xf = compose(ops, nops);
+  if (!m4_inverse(p.xf, &p.inv)) return fail(w, "pattern transform is not invertible");
+  p.uv_mapping = uv_mapping;
+  int nuv = kind == RTB_PAT_TEXTURE_MAP ? 1 : (kind == RTB_PAT_CUBE_MAP ? 6 : 0);
+  for (int i = 0; i < nuv; i++) {
+    if (!uvpats || uvpats[i] < 0 || uvpats[i] >= (int)w->uvs.size()) return fail(w, "bad uv pattern handle");
+    p.uv[i] = uvpats[i];
+  }
+  w->patterns.push_back(p);
+  return (int)w->patterns.size() - 1;
+}
+
+int rth_shape_new(RtbWorld* w, int kind, const RtbXfOp* ops, int nops, const RtbMaterial* material, int shadow,
+                  const float* params, int nparams) {
+  if (kind < RTB_SPHERE || kind > RTB_SMOOTH_TRIANGLE) return fail(w, "bad shape kind");
+  HShape s;
+  s.kind = (uint8_t)kind;
+  s.shadow = shadow != 0;
+  s.mat = material ? *material : default_material();
+  if (s.mat.pattern >= (int)w->patterns.size()) return fail(w, "bad pattern handle");
+  if (kind == RTB_TRIANGLE || kind == RTB_SMOOTH_TRIANGLE) {
+    int need = kind == RTB_TRIANGLE ? 9 : 18;
+    if (!params || nparams < need) return fail(w, "triangle params missing");
+    HTri t{};
+    t.p1 = P3{params[0], params[1], params[2]};
+    t.p2 = P3{params[3], params[4], params[5]};
+    t.p3 = P3{params[6], params[7], params[8]};
+    t.e1 = sub3(t.p2, t.p1);
+    t.e2 = sub3(t.p3, t.p1);
+    if (kind == RTB_TRIANGLE) {
+      t.n1 = normalize3(cross3(t.e2, t.e1));  // triangle.rs:35
+    } else {
+      t.n1 = P3{params[9], params[10], params[11]};
+      t.n2 = P3{params[12], params[13], params[14]};
+      t.n3 = P3{params[15], params[16], params[17]};
+    }
+    w->tris.push_back(t);
+    s.tri = (int)w->tris.size() - 1;
+  } else if ((kind == RTB_CYLINDER || kind == RTB_CONE) && params && nparams >= 3) {
+    s.mn = params[0];
+    s.mx = params[1];
+    s.closed = params[2] != 0.f;
+  }
+  if (!set_shape_transform(s, ops, nops)) return fail(w, "shape transform is not invertible");
+  s.psb = box_transform(w->local_bounds(s), s.xf);  // shapes.rs:318-320
+  w->shapes.push_back(s);
+  return (int)w->shapes.size() - 1;
+}
+
+int rth_group_new(RtbWorld* w, const RtbXfOp* ops, int nops) {
+  int g = w->new_group();
+  w->groups[g].xf = compose(ops, nops);
+  if (!m4_inverse(w->groups[g].xf, &w->groups[g].inv)) return fail(w, "group transform is not invertible");
+  w->touch();
+  return g;
+}
+int rth_group_set_transform(RtbWorld* w, int g, const RtbXfOp* ops, int nops) {
+  if (g < 0 || g >= (int)w->groups.size()) return fail(w, "bad group handle");
+  w->groups[g].xf = compose(ops, nops);
+  if (!m4_inverse(w->groups[g].xf, &w->groups[g].inv)) return fail(w, "group transform is not invertible");
+  w->touch();
+  return 0;
+}
+int rth_group_add_shape(RtbWorld* w, int g, int shape) {
+  if (g < 0 || g >= (int)w->groups.size() || shape < 0 || shape >= (int)w->shapes.size())
+    return fail(w, "bad handle");
+  uint32_t s = w->clone_shape((uint32_t)shape);  // groups.rs:80-85: the group owns a copy
+  w->shapes[s].parent = g;
+  w->groups[g].shapes.push_back(s);
+  w->touch();
+  return 0;
+}
+int rth_group_add_child(RtbWorld* w, int g, int child) {
+  if (g < 0 || g >= (int)w->groups.size() || child < 0 || child >= (int)w->groups.size())
+    return fail(w, "bad group handle");
+  w->attach_child(g, child);
+  w->touch();
+  return 0;
+}
+int rth_group_add_mesh(RtbWorld* w, int g, const RtbMaterial* material, const float* positions, int npositions,
+                       const float* normals, int nnormals, const int32_t* vidx, const int32_t* nidx, int ntriangles) {
+  if (g < 0 || g >= (int)w->groups.size()) return fail(w, "bad group handle");
+  int child = w->new_group();
+  RtbMaterial mat = material ? *material : default_material();
+  w->groups[child].shapes.reserve(ntriangles);
+  w->shapes.reserve(w->shapes.size() + ntriangles);
+  w->tris.reserve(w->tris.size() + ntriangles);
+  for (int t = 0; t < ntriangles; t++) {
+    HTri tr{};
+    P3* ps[3] = {&tr.p1, &tr.p2, &tr.p3};
+    for (int c = 0; c < 3; c++) {
+      int vi = vidx[3 * t + c];
+      if (vi < 0 || vi >= npositions) return fail(w, "mesh position index out of range");
+      *ps[c] = P3{positions[3 * vi], positions[3 * vi + 1], positions[3 * vi + 2]};
+    }
+    tr.e1 = sub3(tr.p2, tr.p1);
+    tr.e2 = sub3(tr.p3, tr.p1);
+    bool smooth = normals && nidx;
+    if (smooth) {
+      P3* ns[3] = {&tr.n1, &tr.n2, &tr.n3};
+      for (int c = 0; c < 3; c++) {
+        int ni = nidx[3 * t + c];
+        if (ni < 0) {
+          smooth = false;
+          break;
+        }
+        if (ni >= nnormals) return fail(w, "mesh normal index out of range");
+        *ns[c] = P3{normals[3 * ni], normals[3 * ni + 1], normals[3 * ni + 2]};
+      }
+    }
+    if (!smooth) {
+      tr.n1 = normalize3(cross3(tr.e2, tr.e1));
+      tr.n2 = tr.n3 = P3{0.f, 0.f, 0.f};
+    }
+    w->tris.push_back(tr);
+    HShape s;
+    s.kind = smooth ? RTB_SMOOTH_TRIANGLE : RTB_TRIANGLE;
+    s.mat = mat;
+    s.tri = (int)w->tris.size() - 1;
+    s.parent = child;
+    s.psb = box_transform(w->local_bounds(s), s.xf);
+    w->shapes.push_back(s);
+    w->groups[child].shapes.push_back((uint32_t)w->shapes.size() - 1);
+  }
+  w->attach_child(g, child);
+  w->touch();
+  return child;
+}
+int rth_group_divide(RtbWorld* w, int g, int threshold) {
+  if (g < 0 || g >= (int)w->groups.size()) return fail(w, "bad group handle");
+  w->divide(g, threshold);
+  w->touch();
+  return 0;
+}
+
+int rth_csg_new(RtbWorld* w, int op, int lkind, int l, int rkind, int r) {
+  HCsg c;
+  c.op = op;
+  auto take = [&](int kind, int id, int* out) -> bool {
+    if (kind == RTB_CHILD_SHAPE) {
+      if (id < 0 || id >= (int)w->shapes.size()) return false;
+      *out = (int)w->clone_shape((uint32_t)id);  // csg.rs:14-24: Box<Shape> owned by the node
+    } else {
+      if (id < 0 || id >= (int)w->csgs.size()) return false;
+      *out = id;
+    }
+    return true;
+  };
+  c.lkind = lkind;
+  c.rkind = rkind;
+  if (!take(lkind, l, &c.l) || !take(rkind, r, &c.r)) return fail(w, "bad csg child handle");
+  w->csgs.push_back(c);
+  return (int)w->csgs.size() - 1;
+}
+
+int rth_world_add_shape(RtbWorld* w, int shape) {
+  if (shape < 0 || shape >= (int)w->shapes.size()) return fail(w, "bad shape handle");
+  uint32_t s = w->clone_shape((uint32_t)shape);
+  w->world_shapes.push_back(s);
+  w->touch();
+  return (int)w->world_shapes.size() - 1;
+}
+int rth_world_add_group(RtbWorld* w, int g, int cache_bounds) {
+  if (g < 0 || g >= (int)w->groups.size()) return fail(w, "bad group handle");
+  if (cache_bounds) {  // groups.rs:190-196
+    w->groups[g].bounds = w->make_bounds(g);
+    w->groups[g].cached = true;
+  }
+  w->world_groups.push_back(g);
+  w->touch();
+  return 0;
+}
+int rth_world_add_csg(RtbWorld* w, int c) {
+  if (c < 0 || c >= (int)w->csgs.size()) return fail(w, "bad csg handle");
+  w->world_csgs.push_back(c);
+  w->touch();
+  return 0;
+}
+int rth_world_add_point_light(RtbWorld* w, const float position[3], const float intensity[3]) {
+  HLight l;
+  l.l.kind = RT_LIGHT_POINT;
+  l.l.usteps = l.l.vsteps = 1;
+  std::memcpy(l.l.position, position, 12);
+  std::memcpy(l.l.intensity, intensity, 12);
+  w->lights.push_back(l);
+  w->touch();
+  return (int)w->lights.size() - 1;
+}
+int rth_world_add_area_light(RtbWorld* w, const float corner[3], const float fu[3], int usteps, const float fv[3],
+                             int vsteps, const float intensity[3]) {
+  if (usteps < 1 || vsteps < 1) return fail(w, "area light steps must be >= 1");
+  HLight l;  // lights.rs:83-103
+  l.l.kind = RT_LIGHT_AREA;
+  l.l.usteps = (uint32_t)usteps;
+  l.l.vsteps = (uint32_t)vsteps;
+  for (int i = 0; i < 3; i++) {
+    l.l.corner[i] = corner[i];
+    l.l.position[i] = corner[i] + (fu[i] + fv[i]) / 2.f;
+    l.l.uvec[i] = fu[i] / (float)usteps;
+    l.l.vvec[i] = fv[i] / (float)vsteps;
+    l.l.intensity[i] = intensity[i];
+  }
+  w->lights.push_back(l);
+  w->touch();
+  return (int)w->lights.size() - 1;
+}
+int rth_world_set_recursion_limit(RtbWorld* w, int limit) {
+  if (limit < 0 || limit > 255) return fail(w, "recursion_limit is a u8 in the reference");
+  w->recursion_limit = limit;
+  w->touch();
+  return 0;
+}
+
+// ---- extras beyond rt_builder.h: the flatten / device plumbing the harness needs ---------
+int rth_set_device(RtbWorld* w, int device) {
+  if (device != w->device) w->drop_device();
+  w->device = device;
+  return 0;
+}
+const RtScene* rth_flatten(RtbWorld* w) {
+  if (!w->flatten()) return nullptr;
+  return &w->flat->view;
+}
+int rth_make_camera(RtbWorld* w, const RtbCamera* cam, RtCamera* out) {
+  if (!make_rt_camera(cam, out)) return fail(w, "camera transform is not invertible");
+  return 0;
+}
+// Ensures the world is flattened and resident on its device; returns the C-ABI handles.
+int rth_device_scene(RtbWorld* w, RtContext** ctx, RtDeviceScene** scene) {
+  if (!w->flatten()) return fail(w, "flatten failed");
+  if (!w->ctx) {
+    int rc = rt_context_create(w->device, &w->ctx);
+    if (rc != RT_OK) return fail(w, "rt_context_create failed (is a GPU visible?)", rc);
+  }
+  if (!w->dscene) {
+    int rc = rt_scene_create(w->ctx, &w->flat->view, &w->dscene);
+    if (rc != RT_OK) return fail(w, std::string("rt_scene_create: ") + rt_last_error(w->ctx), rc);
+  }
+  if (ctx) *ctx = w->ctx;
+  if (scene) *scene = w->dscene;
+  return 0;
+}
+
+// Camera::render(&World) -> Canvas (src/camera.rs:66-84): flatten -> upload -> HIP kernels.
+int rth_render(RtbWorld* w, const RtbCamera* cam, const RtbRenderOptions* opts, float* out_rgb, RtbAux* aux,
+               RtbStats* stats) {
+  RtCamera rc;
+  if (!make_rt_camera(cam, &rc)) return fail(w, "camera transform is not invertible");
+  auto t0 = std::chrono::steady_clock::now();
+  int e = rth_device_scene(w, nullptr, nullptr);
+  if (e != 0) return e;
+  RtRenderOptions ro = to_rt_options(opts);
+  RtAux ra{};
+  if (aux) {
+    ra.hit_mask = aux->hit_mask;
+    ra.object_id = aux->object_id;
+    ra.hit_t = aux->hit_t;
+  }
+  RtStats rs{};
+  int r = rt_render(w->ctx, w->dscene, &rc, &ro, out_rgb, aux ? &ra : nullptr, &rs);
+  if (stats) {
+    stats->primary = rs.primary;
+    stats->shadow = rs.shadow;
+    stats->reflect = rs.reflect;
+    stats->refract = rs.refract;
+    stats->overflow = rs.overflow;
+    stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  }
+  if (r != RT_OK) return fail(w, std::string("rt_render: ") + rt_last_error(w->ctx), r);
+  return 0;
+}
+
+int rth_color_at(RtbWorld* w, const RtbRenderOptions* opts, const float* origins, const float* directions, int n,
+                 int remaining, float* out_rgb, float* hit_t, int32_t* hit_id, float* hit_uv) {
+  int e = rth_device_scene(w, nullptr, nullptr);
+  if (e != 0) return e;
+  RtRenderOptions ro = to_rt_options(opts);
+  int r = rt_color_at(w->ctx, w->dscene, &ro, origins, directions, (uint32_t)n, (uint32_t)remaining, out_rgb, hit_t,
+                      hit_id, hit_uv, nullptr);
+  if (r != RT_OK) return fail(w, std::string("rt_color_at: ") + rt_last_error(w->ctx), r);
+  return 0;
+}
+
+int rth_ray_for_pixel(RtbWorld* w, const RtbCamera* cam, uint32_t px, uint32_t py, float out[6], float* pixel_size) {
+  // Host mirror of Camera::ray_for_pixel (camera.rs:45-64), used by host-logic tests only; the
+  // render kernel generates its own rays.
+  RtCamera c;
+  if (!make_rt_camera(cam, &c)) return fail(w, "camera transform is not invertible");
+  float xoffset = ((float)px + 0.5f) * c.pixel_size, yoffset = ((float)py + 0.5f) * c.pixel_size;
+  float wx = c.half_width - xoffset, wy = c.half_height - yoffset;
+  M4 inv = m4_identity();
+  std::memcpy(inv.a, c.inv_transform, 48);
+  P3 pixel = m4_point(inv, P3{wx, wy, -1.f}), origin = m4_point(inv, P3{0.f, 0.f, 0.f});
+  P3 d = normalize3(sub3(pixel, origin));
+  out[0] = origin.x, out[1] = origin.y, out[2] = origin.z;
+  out[3] = d.x, out[4] = d.y, out[5] = d.z;
+  if (pixel_size) *pixel_size = c.pixel_size;
+  return 0;
+}
+
+}  // extern "C"

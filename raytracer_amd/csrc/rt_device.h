@@ -1,0 +1,1043 @@
+// rt_device.h — device-side ray tracing core for gfx950 (included only by rt_hip.hip).
+//
+// Everything here is f32 with NO fused multiply-add (built with -ffp-contract=off) and with
+// correctly rounded divide/sqrt, evaluated in the reference's operation order, because the
+// parity bar is bit-exact hit / object-id masks against lerouxrgd/raytracer.
+// Reference citations are `file:line` relative to the reference root.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rt_abi.h"
+
+#define RT_MAX_XF_DEPTH 6    // nested non-identity group transforms along one path
+#define RT_MAX_RAY_STACK 8   // pending secondary rays per pixel (recursion_limit + 1 needed)
+#define RT_CSG_CAP 32        // per-ray intersection entries while evaluating one csg tree
+#define RT_CSG_DEPTH 8       // csg tree depth
+#define RT_XS_CAP 96         // per-ray entries for the n1/n2 container walk
+
+namespace rtd {
+
+struct V3 {
+  float x, y, z;
+};
+struct Ray {
+  V3 o, d;
+};
+
+__device__ __forceinline__ V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 operator-(V3 a) { return V3{-a.x, -a.y, -a.z}; }
+__device__ __forceinline__ V3 operator*(float s, V3 a) { return V3{s * a.x, s * a.y, s * a.z}; }  // tuples.rs:83-93
+__device__ __forceinline__ V3 mulc(V3 a, V3 b) { return V3{a.x * b.x, a.y * b.y, a.z * b.z}; }      // tuples.rs:70-80
+__device__ __forceinline__ V3 operator/(V3 a, float s) { return V3{a.x / s, a.y / s, a.z / s}; }    // tuples.rs:96-106
+// dot / magnitude of vectors: the w terms of the reference (tuples.rs:232-242) are 0*0 and drop out.
+__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ float magnitude(V3 a) { return __builtin_sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
+__device__ __forceinline__ V3 normalize(V3 a) { return a / magnitude(a); }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) {  // tuples.rs:244-250
+  return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+__device__ __forceinline__ V3 reflect(V3 in, V3 n) { return in - (2.f * dot(in, n)) * n; }  // tuples.rs:252-254
+
+// ordered-float total order (NaN greatest, NaN == NaN)
+__device__ __forceinline__ bool of_gt(float a, float b) { return (a > b) || ((a != a) && (b == b)); }
+__device__ __forceinline__ bool of_eq(float a, float b) { return (a == b) || ((a != a) && (b != b)); }
+__device__ __forceinline__ float of_max(float a, float b) { return of_gt(a, b) ? a : b; }
+__device__ __forceinline__ float of_min(float a, float b) { return of_gt(a, b) ? b : a; }
+
+struct Scene {
+  const RtXform* xforms;
+  const RtShape* shapes;
+  const float4* tri_geom;     // 3 float4 per triangle
+  const float4* tri_normals;  // 3 float4 per triangle
+  const RtNode* nodes;
+  const RtCsgNode* csg_nodes;
+  const RtCsgRoot* csg_roots;
+  const RtMaterial* materials;
+  const RtPattern* patterns;
+  const RtUvPattern* uvpatterns;
+  const RtImage* images;
+  const float* texels;
+  const RtLight* lights;
+  uint32_t n_shapes, n_nodes, n_csg_roots, n_lights, n_loose, recursion_limit;
+  uint32_t flags;  // RT_RENDER_*
+};
+
+// Matrix<4,4> * Point / Vector (matrices.rs:68-80, :220-236): row sums left to right.
+__device__ __forceinline__ V3 xf_point(const float* m, V3 p) {
+  return V3{((m[0] * p.x + m[1] * p.y) + m[2] * p.z) + m[3], ((m[4] * p.x + m[5] * p.y) + m[6] * p.z) + m[7],
+            ((m[8] * p.x + m[9] * p.y) + m[10] * p.z) + m[11]};
+}
+__device__ __forceinline__ V3 xf_vector(const float* m, V3 v) {
+  return V3{(m[0] * v.x + m[1] * v.y) + m[2] * v.z, (m[4] * v.x + m[5] * v.y) + m[6] * v.z,
+            (m[8] * v.x + m[9] * v.y) + m[10] * v.z};
+}
+// inverse.transpose() * normal (shapes.rs:281-285): column sums of the 3x3 block.
+__device__ __forceinline__ V3 xf_normal(const float* m, V3 n) {
+  return V3{(m[0] * n.x + m[4] * n.y) + m[8] * n.z, (m[1] * n.x + m[5] * n.y) + m[9] * n.z,
+            (m[2] * n.x + m[6] * n.y) + m[10] * n.z};
+}
+__device__ __forceinline__ Ray xf_ray(const Scene& sc, uint32_t xform, Ray r) {  // rays.rs:19-24
+  const float* m = sc.xforms[xform].m;
+  return Ray{xf_point(m, r.o), xf_vector(m, r.d)};
+}
+
+// Cube::check_axis (shapes/cube.rs:67-85)
+__device__ __forceinline__ void check_axis(float origin, float direction, float mn, float mx, float& tmin,
+                                           float& tmax) {
+  float a = mn - origin, b = mx - origin;
+  if (__builtin_fabsf(direction) >= 1e-4f) {
+    a = a / direction;
+    b = b / direction;
+  } else {
+    a = a * __builtin_inff();
+    b = b * __builtin_inff();
+  }
+  if (a > b) {
+    tmin = b;
+    tmax = a;
+  } else {
+    tmin = a;
+    tmax = b;
+  }
+}
+// BoundingBox::intersects (bounds.rs:91-123) / Cube::local_intersect (cube.rs:87-114)
+__device__ __forceinline__ bool slab(const Ray& r, V3 mn, V3 mx, float& tmin, float& tmax) {
+  float x0, x1, y0, y1, z0, z1;
+  check_axis(r.o.x, r.d.x, mn.x, mx.x, x0, x1);
+  check_axis(r.o.y, r.d.y, mn.y, mx.y, y0, y1);
+  check_axis(r.o.z, r.d.z, mn.z, mx.z, z0, z1);
+  tmin = of_max(of_max(x0, y0), z0);
+  tmax = of_min(of_min(x1, y1), z1);
+  return !of_gt(tmin, tmax);
+}
+
+// Local intersections: fill ts[] in the reference's insertion order, return the count.
+__device__ __forceinline__ int isect_sphere(const Ray& r, float* ts) {  // sphere.rs:64-80
+  float a = dot(r.d, r.d);
+  float b = 2.f * dot(r.d, r.o);
+  float c = dot(r.o, r.o) - 1.f;
+  float disc = b * b - 4.f * a * c;
+  if (disc < 0.f) return 0;
+  float sq = __builtin_sqrtf(disc);
+  ts[0] = (-b - sq) / (2.f * a);
+  ts[1] = (-b + sq) / (2.f * a);
+  return 2;
+}
+__device__ __forceinline__ int isect_plane(const Ray& r, float* ts) {  // plane.rs:66-73
+  if (__builtin_fabsf(r.d.y) < 1e-4f) return 0;
+  ts[0] = -r.o.y / r.d.y;
+  return 1;
+}
+__device__ __forceinline__ int isect_cube(const Ray& r, float* ts) {  // cube.rs:87-114
+  float tmin, tmax;
+  if (!slab(r, v3(-1.f, -1.f, -1.f), v3(1.f, 1.f, 1.f), tmin, tmax)) return 0;
+  ts[0] = tmin;
+  ts[1] = tmax;
+  return 2;
+}
+__device__ __forceinline__ bool cap_cyl(const Ray& r, float t) {  // cylinder.rs:89-93
+  float x = r.o.x + t * r.d.x, z = r.o.z + t * r.d.z;
+  return (x * x + z * z) <= 1.f;
+}
+__device__ __forceinline__ bool cap_cone(const Ray& r, float t, float y) {  // cone.rs:90-94
+  float x = r.o.x + t * r.d.x, z = r.o.z + t * r.d.z;
+  return (x * x + z * z) <= __builtin_fabsf(y);
+}
+// cylinder.rs:95-156 — two Option slots; caps fill the first free slot; output in slot order.
+__device__ __forceinline__ int isect_cylinder(const Ray& r, float mn, float mx, bool closed, float* ts) {
+  float s0 = 0.f, s1 = 0.f;
+  bool h0 = false, h1 = false;
+  float a = r.d.x * r.d.x + r.d.z * r.d.z;
+  if (!(__builtin_fabsf(a) < 1e-4f)) {
+    float b = 2.f * r.o.x * r.d.x + 2.f * r.o.z * r.d.z;
+    float c = r.o.x * r.o.x + r.o.z * r.o.z - 1.f;
+    float disc = b * b - 4.f * a * c;
+    if (disc < 0.f) return 0;
+    float sq = __builtin_sqrtf(disc);
+    float t0 = (-b - sq) / (2.f * a), t1 = (-b + sq) / (2.f * a);
+    if (t0 > t1) {
+      float tmp = t0;
+      t0 = t1;
+      t1 = tmp;
+    }
+    float y0 = r.o.y + t0 * r.d.y;
+    if (mn < y0 && y0 < mx) {
+      h0 = true;
+      s0 = t0;
+    }
+    float y1 = r.o.y + t1 * r.d.y;
+    if (mn < y1 && y1 < mx) {
+      h1 = true;
+      s1 = t1;
+    }
+  }
+  if (closed && !(__builtin_fabsf(r.d.y) < 1e-4f)) {
+    float t = (mn - r.o.y) / r.d.y;
+    if (cap_cyl(r, t)) {
+      if (!h0) {
+        h0 = true;
+        s0 = t;
+      } else if (!h1) {
+        h1 = true;
+        s1 = t;
+      }
+    }
+    t = (mx - r.o.y) / r.d.y;
+    if (cap_cyl(r, t)) {
+      if (!h0) {
+        h0 = true;
+        s0 = t;
+      } else if (!h1) {
+        h1 = true;
+        s1 = t;
+      }
+    }
+  }
+  int n = 0;
+  if (h0) ts[n++] = s0;
+  if (h1) ts[n++] = s1;
+  return n;
+}
+// cone.rs:96-165 — four Option slots.
+__device__ __forceinline__ int isect_cone(const Ray& r, float mn, float mx, bool closed, float* ts) {
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  bool h[4] = {false, false, false, false};
+  float a = r.d.x * r.d.x - r.d.y * r.d.y + r.d.z * r.d.z;
+  float b = 2.f * r.o.x * r.d.x - 2.f * r.o.y * r.d.y + 2.f * r.o.z * r.d.z;
+  float c = r.o.x * r.o.x - r.o.y * r.o.y + r.o.z * r.o.z;
+  if (__builtin_fabsf(a) < 1e-4f) {
+    if (__builtin_fabsf(b) < 1e-4f) return 0;
+    h[0] = true;
+    s[0] = -c / (2.f * b);
+  } else {
+    float disc = b * b - 4.f * a * c;
+    if (disc < 0.f) return 0;
+    float sq = __builtin_sqrtf(disc);
+    float t0 = (-b - sq) / (2.f * a), t1 = (-b + sq) / (2.f * a);
+    if (t0 > t1) {
+      float tmp = t0;
+      t0 = t1;
+      t1 = tmp;
+    }
+    float y0 = r.o.y + t0 * r.d.y;
+    if (mn < y0 && y0 < mx) {
+      h[0] = true;
+      s[0] = t0;
+    }
+    float y1 = r.o.y + t1 * r.d.y;
+    if (mn < y1 && y1 < mx) {
+      h[1] = true;
+      s[1] = t1;
+    }
+  }
+  if (closed && !(__builtin_fabsf(r.d.y) < 1e-4f)) {
+    float t = (mn - r.o.y) / r.d.y;
+    if (cap_cone(r, t, mn)) {
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+        if (!h[i]) {
+          h[i] = true;
+          s[i] = t;
+          break;
+        }
+    }
+    t = (mx - r.o.y) / r.d.y;
+    if (cap_cone(r, t, mx)) {
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+        if (!h[i]) {
+          h[i] = true;
+          s[i] = t;
+          break;
+        }
+    }
+  }
+  int n = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+    if (h[i]) ts[n++] = s[i];
+  return n;
+}
+// triangle.rs:93-115 / smooth_triangle.rs:96-118 (Möller–Trumbore)
+__device__ __forceinline__ bool isect_triangle(const Ray& r, V3 p1, V3 e1, V3 e2, float& t, float& u, float& v) {
+  V3 dir_cross_e2 = cross(r.d, e2);
+  float det = dot(e1, dir_cross_e2);
+  if (__builtin_fabsf(det) < 1e-4f) return false;
+  float f = 1.f / det;
+  V3 p1_to_origin = r.o - p1;
+  u = f * dot(p1_to_origin, dir_cross_e2);
+  if (!(0.f <= u && u <= 1.f)) return false;
+  V3 origin_cross_e1 = cross(p1_to_origin, e1);
+  v = f * dot(r.d, origin_cross_e1);
+  if (v < 0.f || (u + v) > 1.f) return false;
+  t = f * dot(e2, origin_cross_e1);
+  return true;
+}
+__device__ __forceinline__ void load_tri(const Scene& sc, uint32_t prim, V3& p1, V3& e1, V3& e2) {
+  const float4* g = sc.tri_geom + 3u * (size_t)prim;
+  float4 a = g[0], b = g[1], c = g[2];
+  p1 = v3(a.x, a.y, a.z);
+  e1 = v3(b.x, b.y, b.z);
+  e2 = v3(c.x, c.y, c.z);
+}
+
+// ---------------------------------------------------------------------------------------
+// Sinks: what a traversal does with each intersection it finds.
+// ---------------------------------------------------------------------------------------
+// Intersections::hit() (intersections.rs:94-96) over the stable t-sorted list:
+// minimise (t, insertion rank) over t > 0.  Traversal order is therefore free.
+struct ClosestSink {
+  float t, u, v;
+  int shape;
+  __device__ __forceinline__ void init() {
+    t = __builtin_inff();
+    u = v = 0.f;
+    shape = -1;
+  }
+  __device__ __forceinline__ void add(float tt, uint32_t s, float uu, float vv) {
+    if (tt > 0.f && (shape < 0 || tt < t || (tt == t && (int)s < shape))) {
+      t = tt;
+      shape = (int)s;
+      u = uu;
+      v = vv;
+    }
+  }
+  __device__ __forceinline__ float limit() const { return shape < 0 ? __builtin_inff() : t; }
+  static constexpr bool wants_negative = false;
+};
+// Every intersection with t <= tlimit (total order), for the n1/n2 container walk.
+struct CollectSink {
+  float* ts;
+  uint32_t* ss;
+  int n;
+  int overflow;
+  float tlimit;
+  __device__ __forceinline__ void add(float tt, uint32_t s, float, float) {
+    if (!of_gt(tt, tlimit)) {
+      if (n < RT_XS_CAP) {
+        ts[n] = tt;
+        ss[n] = s;
+        n++;
+      } else {
+        overflow = 1;
+      }
+    }
+  }
+  __device__ __forceinline__ float limit() const { return tlimit; }
+  static constexpr bool wants_negative = true;
+};
+
+// Shape::intersect (shapes.rs:204-246): inverse-transform the ray, dispatch on kind.
+template <class Sink>
+__device__ __forceinline__ void shape_intersect(const Scene& sc, uint32_t si, const Ray& ray, Sink& sink) {
+  const uint4* raw = reinterpret_cast<const uint4*>(sc.shapes + si);
+  uint4 w0 = raw[0], w1 = raw[1];
+  uint32_t kf = w0.x, xform = w0.y, prim = w1.y;
+  float mn = __uint_as_float(w1.z), mx = __uint_as_float(w1.w);
+  Ray local = xform ? xf_ray(sc, xform, ray) : ray;
+  float ts[4];
+  int n = 0;
+  switch (kf & RT_SHAPE_KIND_MASK) {
+    case RT_SPHERE: n = isect_sphere(local, ts); break;
+    case RT_PLANE: n = isect_plane(local, ts); break;
+    case RT_CUBE: n = isect_cube(local, ts); break;
+    case RT_CYLINDER: n = isect_cylinder(local, mn, mx, (kf & RT_SHAPE_CLOSED) != 0, ts); break;
+    case RT_CONE: n = isect_cone(local, mn, mx, (kf & RT_SHAPE_CLOSED) != 0, ts); break;
+    default: {
+      V3 p1, e1, e2;
+      load_tri(sc, prim, p1, e1, e2);
+      float t, u, v;
+      if (isect_triangle(local, p1, e1, e2, t, u, v)) sink.add(t, si, u, v);
+      return;
+    }
+  }
+  for (int i = 0; i < n; i++) sink.add(ts[i], si, 0.f, 0.f);
+}
+
+// ---------------------------------------------------------------------------------------
+// CSG (csg.rs:26-124), evaluated bottom-up over the post-ordered node array with one
+// per-ray entry list; entries are kept sorted by (t total order, insertion rank), which is
+// what the reference's nested stable sorts produce (DESIGN.md "CSG").
+// ---------------------------------------------------------------------------------------
+struct CsgList {
+  float t[RT_CSG_CAP];
+  uint32_t s[RT_CSG_CAP];
+  int n;
+  int overflow;
+  __device__ __forceinline__ void add(float tt, uint32_t ss, float, float) {
+    if (n < RT_CSG_CAP) {
+      t[n] = tt;
+      s[n] = ss;
+      n++;
+    } else {
+      overflow = 1;
+    }
+  }
+};
+__device__ __forceinline__ bool vclass_eq(uint32_t a, uint32_t b) { return a == b && a != RT_VCLASS_NEVER; }
+__device__ __forceinline__ bool entry_less(float ta, uint32_t sa, float tb, uint32_t sb) {
+  return of_gt(tb, ta) || (of_eq(ta, tb) && sa < sb);
+}
+// Drop an entry that is == its successor (BTreeMap bulk build).
+__device__ inline int dedup_sorted(const Scene& sc, float* t, uint32_t* s, int lo, int hi) {
+  int w = lo;
+  for (int i = lo; i < hi; i++) {
+    if (i + 1 < hi && of_eq(t[i], t[i + 1]) && vclass_eq(sc.shapes[s[i]].vclass, sc.shapes[s[i + 1]].vclass)) continue;
+    t[w] = t[i];
+    s[w] = s[i];
+    w++;
+  }
+  return w;
+}
+__device__ inline void sort_entries(float* t, uint32_t* s, int lo, int hi) {
+  for (int i = lo + 1; i < hi; i++) {
+    float ti = t[i];
+    uint32_t si = s[i];
+    int j = i - 1;
+    while (j >= lo && entry_less(ti, si, t[j], s[j])) {
+      t[j + 1] = t[j];
+      s[j + 1] = s[j];
+      j--;
+    }
+    t[j + 1] = ti;
+    s[j + 1] = si;
+  }
+}
+__device__ __forceinline__ bool csg_allowed(uint32_t op, bool l_hit, bool in_l, bool in_r) {  // csg.rs:116-124
+  if (op == RT_CSG_UNION) return (l_hit && !in_r) || (!l_hit && !in_l);
+  if (op == RT_CSG_INTERSECT) return (l_hit && in_r) || (!l_hit && in_l);
+  return (l_hit && !in_r) || (!l_hit && in_l);
+}
+// Evaluates one top-level csg; on return L.t/L.s[0..L.n) is Csg::local_intersect(ray).
+__device__ inline void csg_eval(const Scene& sc, RtCsgRoot root, const Ray& ray, CsgList& L) {
+  int seg[RT_CSG_DEPTH];
+  int sp = 0;
+  L.n = 0;
+  for (uint32_t k = root.first; k < root.first + root.count; k++) {
+    const uint4* raw = reinterpret_cast<const uint4*>(sc.csg_nodes + k);
+    uint4 w0 = raw[0], w1 = raw[1], w2 = raw[2];
+    uint32_t op = w0.w, flags = w1.w;
+    int nseg = ((flags & RT_CSG_LEFT_IS_SHAPE) ? 0 : 1) + ((flags & RT_CSG_RIGHT_IS_SHAPE) ? 0 : 1);
+    int start = nseg ? seg[sp - nseg] : L.n;
+    sp -= nseg;
+    float tmin, tmax;
+    V3 bmin = v3(__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z));
+    V3 bmax = v3(__uint_as_float(w1.x), __uint_as_float(w1.y), __uint_as_float(w1.z));
+    if (!slab(ray, bmin, bmax, tmin, tmax)) {  // csg.rs:27-29
+      L.n = start;
+      seg[sp++] = start;
+      continue;
+    }
+    if (flags & RT_CSG_LEFT_IS_SHAPE) shape_intersect(sc, w2.x, ray, L);
+    if (flags & RT_CSG_RIGHT_IS_SHAPE) shape_intersect(sc, w2.y, ray, L);
+    sort_entries(L.t, L.s, start, L.n);
+    L.n = dedup_sorted(sc, L.t, L.s, start, L.n);
+    // filter_intersections (csg.rs:51-72)
+    bool in_l = false, in_r = false;
+    int w = start;
+    uint32_t left_lo = w2.z, left_hi = w2.w;
+    for (int i = start; i < L.n; i++) {
+      uint32_t s = L.s[i];
+      uint32_t vc = sc.shapes[s].vclass;
+      bool l_hit;
+      if (flags & RT_CSG_LEFT_IS_SHAPE) {
+        l_hit = vclass_eq(sc.shapes[w2.x].vclass, vc);
+      } else {  // Csg::includes (csg.rs:74-85): by value over the left subtree's leaves
+        l_hit = false;
+        for (uint32_t q = left_lo; q < left_hi && !l_hit; q++) l_hit = vclass_eq(sc.shapes[q].vclass, vc);
+      }
+      if (csg_allowed(op, l_hit, in_l, in_r)) {
+        L.t[w] = L.t[i];
+        L.s[w] = s;
+        w++;
+      }
+      if (l_hit)
+        in_l = !in_l;
+      else
+        in_r = !in_r;
+    }
+    L.n = dedup_sorted(sc, L.t, L.s, start, w);  // `result.into()` (csg.rs:71)
+    seg[sp++] = start;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// World::intersect (world.rs:44-62) as one traversal feeding a sink.
+// Groups: stackless depth-first walk over the DFS-ordered node array (skip pointers); the ray is
+// re-expressed in a group's space when the group has a non-identity transform (groups.rs:127-133)
+// and restored when the walk leaves that subtree.
+// ---------------------------------------------------------------------------------------
+template <class Sink>
+__device__ inline void world_intersect(const Scene& sc, const Ray& ray, Sink& sink, int& csg_overflow) {
+  // csgs first (world.rs:45-49)
+  if (sc.n_csg_roots) {
+    CsgList L;
+    L.overflow = 0;
+    for (uint32_t c = 0; c < sc.n_csg_roots; c++) {
+      csg_eval(sc, sc.csg_roots[c], ray, L);
+      for (int i = 0; i < L.n; i++) sink.add(L.t[i], L.s[i], __builtin_nanf(""), __builtin_nanf(""));
+    }
+    csg_overflow |= L.overflow;
+  }
+  // groups (world.rs:51-54)
+  {
+    Ray saved[RT_MAX_XF_DEPTH];
+    uint32_t restore_at[RT_MAX_XF_DEPTH];
+    int rs = 0;
+    Ray cur = ray;
+    const bool prune = !(sc.flags & RT_RENDER_NO_PRUNE);
+    uint32_t i = 0;
+    while (i < sc.n_nodes) {
+      while (rs > 0 && i >= restore_at[rs - 1]) cur = saved[--rs];
+      const uint4* raw = reinterpret_cast<const uint4*>(sc.nodes + i);
+      uint4 w0 = raw[0], w1 = raw[1], w2 = raw[2], w3 = raw[3];
+      uint32_t xform = w0.w, flags = w1.w, skip = w2.z;
+      if (xform) {
+        saved[rs] = cur;
+        restore_at[rs] = skip;
+        rs++;
+        cur = xf_ray(sc, xform, cur);
+      }
+      float tmin, tmax;
+      V3 bmin = v3(__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z));
+      V3 bmax = v3(__uint_as_float(w1.x), __uint_as_float(w1.y), __uint_as_float(w1.z));
+      if (!slab(cur, bmin, bmax, tmin, tmax)) {  // groups.rs:111-113
+        i = skip;
+        continue;
+      }
+      if (prune && (flags & RT_NODE_PRUNABLE)) {
+        // Distance pruning (not in the reference): a box that truly encloses its subtree cannot
+        // hold a hit beyond its exit or before its entry; margins cover f32 rounding of t.
+        float lim = sink.limit();
+        if (tmin > lim + (1e-4f * __builtin_fabsf(lim) + 1e-4f)) {
+          i = skip;
+          continue;
+        }
+        if (!Sink::wants_negative && tmax < -(1e-4f * __builtin_fabsf(tmax) + 1e-4f)) {
+          i = skip;
+          continue;
+        }
+      }
+      uint32_t first_shape = w2.x, n_shapes = w2.y;
+      if (flags & RT_NODE_ALL_TRIS) {
+        uint32_t first_tri = w3.x;
+        for (uint32_t k = 0; k < n_shapes; k++) {
+          V3 p1, e1, e2;
+          load_tri(sc, first_tri + k, p1, e1, e2);
+          float t, u, v;
+          if (isect_triangle(cur, p1, e1, e2, t, u, v)) sink.add(t, first_shape + k, u, v);
+        }
+      } else {
+        for (uint32_t k = 0; k < n_shapes; k++) shape_intersect(sc, first_shape + k, cur, sink);
+      }
+      i = i + 1;
+    }
+  }
+  // loose shapes (world.rs:56-59): the last n_loose entries of shapes[]
+  for (uint32_t k = sc.n_shapes - sc.n_loose; k < sc.n_shapes; k++) shape_intersect(sc, k, ray, sink);
+}
+
+// ---------------------------------------------------------------------------------------
+// Shape::normal_at (shapes.rs:187-202) with the parent-chain walks of world_to_object /
+// normal_to_world (shapes.rs:272-292, groups.rs:139-164).  Identity levels are exact no-ops on
+// points and idempotent renormalisations on normals (DESIGN.md "Parent chains").
+// ---------------------------------------------------------------------------------------
+__device__ inline V3 world_to_object(const Scene& sc, uint32_t shape_xform, int parent, V3 p) {
+  int chain[RT_MAX_XF_DEPTH];
+  int n = 0;
+  int g = parent;
+  while (g >= 0) {
+    int q = sc.nodes[g].next_xf;
+    if (q < 0) break;
+    if (n < RT_MAX_XF_DEPTH) chain[n++] = q;
+    g = sc.nodes[q].parent;
+  }
+  for (int i = n - 1; i >= 0; i--) p = xf_point(sc.xforms[sc.nodes[chain[i]].xform].m, p);
+  if (shape_xform) p = xf_point(sc.xforms[shape_xform].m, p);
+  return p;
+}
+__device__ __forceinline__ V3 renorm_identity(V3 n, uint32_t levels) {
+  // each identity level is `normalize(I^T n)`; once |n| rounds to exactly 1 further levels are no-ops
+  for (uint32_t k = 0; k < levels; k++) {
+    float m = magnitude(n);
+    if (m == 1.f) break;
+    n = n / m;
+  }
+  return n;
+}
+__device__ inline V3 normal_to_world(const Scene& sc, uint32_t shape_xform, int parent, V3 n) {
+  if (shape_xform)
+    n = normalize(xf_normal(sc.xforms[shape_xform].m, n));
+  else
+    n = normalize(n);
+  int g = parent;
+  while (g >= 0) {
+    const RtNode& nd = sc.nodes[g];
+    n = renorm_identity(n, nd.idrun);
+    int q = nd.next_xf;
+    if (q < 0) break;
+    n = normalize(xf_normal(sc.xforms[sc.nodes[q].xform].m, n));
+    g = sc.nodes[q].parent;
+  }
+  return n;
+}
+__device__ inline V3 local_normal_at(const Scene& sc, uint32_t kf, float mn, float mx, uint32_t prim, V3 lp, float hu,
+                                     float hv) {
+  switch (kf & RT_SHAPE_KIND_MASK) {
+    case RT_SPHERE: return lp;                    // sphere.rs:82-84
+    case RT_PLANE: return v3(0.f, 1.f, 0.f);      // plane.rs:75-77
+    case RT_CUBE: {                               // cube.rs:116-133
+      float ax = __builtin_fabsf(lp.x), ay = __builtin_fabsf(lp.y), az = __builtin_fabsf(lp.z);
+      float maxc = of_max(of_max(ax, ay), az);
+      if (ax == maxc) return v3(lp.x, 0.f, 0.f);
+      if (ay == maxc) return v3(0.f, lp.y, 0.f);
+      return v3(0.f, 0.f, lp.z);
+    }
+    case RT_CYLINDER: {  // cylinder.rs:158-167
+      float dist = lp.x * lp.x + lp.z * lp.z;
+      if (dist < 1.f && lp.y >= mx - 1e-4f) return v3(0.f, 1.f, 0.f);
+      if (dist < 1.f && lp.y <= mn + 1e-4f) return v3(0.f, -1.f, 0.f);
+      return v3(lp.x, 0.f, lp.z);
+    }
+    case RT_CONE: {  // cone.rs:167-180
+      float dist = lp.x * lp.x + lp.z * lp.z;
+      if (dist < 1.f && lp.y >= mx - 1e-4f) return v3(0.f, 1.f, 0.f);
+      if (dist < 1.f && lp.y <= mn + 1e-4f) return v3(0.f, -1.f, 0.f);
+      float y = __builtin_sqrtf(lp.x * lp.x + lp.z * lp.z);
+      if (lp.y > 0.f) y = -y;
+      return v3(lp.x, y, lp.z);
+    }
+    case RT_TRIANGLE: {  // triangle.rs:89-91
+      float4 a = sc.tri_normals[3u * (size_t)prim];
+      return v3(a.x, a.y, a.z);
+    }
+    default: {  // smooth_triangle.rs:92-94
+      const float4* g = sc.tri_normals + 3u * (size_t)prim;
+      float4 a = g[0], b = g[1], c = g[2];
+      V3 n1 = v3(a.x, a.y, a.z), n2 = v3(b.x, b.y, b.z), n3 = v3(c.x, c.y, c.z);
+      return (hu * n2 + hv * n3) + (1.f - hu - hv) * n1;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Patterns (patterns.rs:79-91, patterns/*.rs)
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float rem_euclid1(float x) {
+  float r = fmodf(x, 1.f);
+  return r < 0.f ? r + 1.f : r;
+}
+__device__ __forceinline__ uint32_t round_to_u32(float x) {  // `x.round() as u32`
+  float r = roundf(x);
+  if (!(r > 0.f)) return 0u;
+  if (r >= 4294967296.f) return 0xFFFFFFFFu;
+  return (uint32_t)r;
+}
+__device__ inline V3 uv_pattern_at(const Scene& sc, int id, float u, float v) {
+  const RtUvPattern& p = sc.uvpatterns[id];
+  if (p.kind == RT_UV_CHECKER) {  // uv_pattern.rs:44-52
+    float u2 = floorf(u * p.width), v2 = floorf(v * p.height);
+    int k = (fmodf(u2 + v2, 2.f) == 0.f) ? 0 : 1;
+    return v3(p.c[k][0], p.c[k][1], p.c[k][2]);
+  }
+  if (p.kind == RT_UV_ALIGN_CHECK) {  // uv_pattern.rs:89-104
+    int k = 0;
+    if (v > 0.8f) {
+      if (u < 0.2f)
+        k = 1;
+      else if (u > 0.8f)
+        k = 2;
+    } else if (v < 0.2f) {
+      if (u < 0.2f)
+        k = 3;
+      else if (u > 0.8f)
+        k = 4;
+    }
+    return v3(p.c[k][0], p.c[k][1], p.c[k][2]);
+  }
+  // image, uv_pattern.rs:122-132
+  const RtImage& im = sc.images[p.image];
+  float vv = 1.f - v;
+  float x = u * ((float)im.width - 1.f), y = vv * ((float)im.height - 1.f);
+  uint32_t xi = round_to_u32(x), yi = round_to_u32(y);
+  if (xi >= im.width) xi = im.width - 1;
+  if (yi >= im.height) yi = im.height - 1;
+  const float* px = sc.texels + im.offset + ((size_t)yi * im.width + xi) * 3u;
+  return v3(px[0], px[1], px[2]);
+}
+__device__ inline V3 pattern_at(const Scene& sc, const RtPattern& p, V3 pp) {
+  const float PI_F = 3.14159265358979323846f;
+  V3 a = v3(p.a[0], p.a[1], p.a[2]), b = v3(p.b[0], p.b[1], p.b[2]);
+  switch (p.kind) {
+    case RT_PAT_STRIPED: return fmodf(floorf(pp.x), 2.f) == 0.f ? a : b;  // striped.rs:28-34
+    case RT_PAT_GRADIENT: {                                               // gradient.rs:28-32
+      V3 distance = b - a;
+      float fraction = pp.x - floorf(pp.x);
+      return a + fraction * distance;
+    }
+    case RT_PAT_RING:  // ring.rs:28-39
+      return fmodf(floorf(__builtin_sqrtf(pp.x * pp.x + pp.z * pp.z)), 2.f) == 0.f ? a : b;
+    case RT_PAT_CHECKER:  // checker.rs:28-36
+      return fmodf(floorf(pp.x) + floorf(pp.y) + floorf(pp.z), 2.f) == 0.f ? a : b;
+    case RT_PAT_XYZ_RGB: return pp;  // xyz_rgb.rs:24-26
+    case RT_PAT_TEXTURE_MAP: {       // texture_map.rs:31-34, :59-114
+      float u, v;
+      if (p.uv_mapping == RT_UVMAP_SPHERICAL) {
+        float theta = atan2f(pp.x, pp.z);
+        float radius = magnitude(pp);
+        float phi = acosf(pp.y / radius);
+        float raw_u = theta / (2.f * PI_F);
+        u = 1.f - (raw_u + 0.5f);
+        v = 1.f - phi / PI_F;
+      } else if (p.uv_mapping == RT_UVMAP_PLANAR) {
+        u = rem_euclid1(pp.x);
+        v = rem_euclid1(pp.z);
+      } else {
+        float theta = atan2f(pp.x, pp.z);
+        float raw_u = theta / (2.f * PI_F);
+        u = 1.f - (raw_u + 0.5f);
+        v = rem_euclid1(pp.y);
+      }
+      return uv_pattern_at(sc, p.uv[0], u, v);
+    }
+    default: {  // cube_map.rs:46-138; faces: 0 left,1 front,2 right,3 back,4 up,5 down
+      float coord = of_max(of_max(__builtin_fabsf(pp.x), __builtin_fabsf(pp.y)), __builtin_fabsf(pp.z));
+      int face;
+      float u, v;
+      if (coord == pp.x) {
+        face = 2;
+        u = fmodf(1.f - pp.z, 2.f) / 2.f;
+        v = fmodf(pp.y + 1.f, 2.f) / 2.f;
+      } else if (coord == -pp.x) {
+        face = 0;
+        u = fmodf(pp.z + 1.f, 2.f) / 2.f;
+        v = fmodf(pp.y + 1.f, 2.f) / 2.f;
+      } else if (coord == pp.y) {
+        face = 4;
+        u = fmodf(pp.x + 1.f, 2.f) / 2.f;
+        v = fmodf(1.f - pp.z, 2.f) / 2.f;
+      } else if (coord == -pp.y) {
+        face = 5;
+        u = fmodf(pp.x + 1.f, 2.f) / 2.f;
+        v = fmodf(pp.z + 1.f, 2.f) / 2.f;
+      } else if (coord == pp.z) {
+        face = 1;
+        u = fmodf(pp.x + 1.f, 2.f) / 2.f;
+        v = fmodf(pp.y + 1.f, 2.f) / 2.f;
+      } else {
+        face = 3;
+        u = fmodf(1.f - pp.x, 2.f) / 2.f;
+        v = fmodf(pp.y + 1.f, 2.f) / 2.f;
+      }
+      return uv_pattern_at(sc, p.uv[face], u, v);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Area-light jitter (lights.rs:105-121): counter hash shared bit-for-bit with the oracle.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t mix32(uint32_t h) {
+  h ^= h >> 16;
+  h *= 0x85ebca6bu;
+  h ^= h >> 13;
+  h *= 0xc2b2ae35u;
+  h ^= h >> 16;
+  return h;
+}
+__device__ __forceinline__ float counter_jitter(uint64_t seed, uint32_t pixel, uint32_t path, uint32_t light,
+                                                uint32_t cell, uint32_t site, uint32_t which) {
+  uint32_t h = mix32((uint32_t)seed ^ 0x9e3779b9u);
+  h = mix32(h ^ (uint32_t)(seed >> 32));
+  h = mix32(h ^ pixel);
+  h = mix32(h ^ path);
+  h = mix32(h ^ light);
+  h = mix32(h ^ cell);
+  h = mix32(h ^ (site * 2u + which));
+  return (float)(h >> 8) * (1.0f / 16777216.0f);
+}
+
+struct RenderParams {
+  uint32_t jitter_mode;
+  float jitter_value;
+  uint64_t seed;
+};
+struct Counters {
+  uint32_t primary, shadow, reflect, refract, overflow;
+};
+
+struct Hit {
+  float t, u, v;
+  int shape;
+};
+
+// Intersections::hit() of World::intersect(ray).
+__device__ inline Hit trace_closest(const Scene& sc, const Ray& ray, Counters& cn) {
+  ClosestSink sink;
+  sink.init();
+  int ovf = 0;
+  world_intersect(sc, ray, sink, ovf);
+  cn.overflow += ovf;
+  return Hit{sink.t, sink.u, sink.v, sink.shape};
+}
+
+// World::is_shadowed (world.rs:101-111): closest-hit semantics.
+__device__ inline bool is_shadowed(const Scene& sc, V3 light_position, V3 p, Counters& cn) {
+  V3 v = light_position - p;
+  float distance = magnitude(v);
+  V3 direction = v / distance;
+  cn.shadow++;
+  Hit h = trace_closest(sc, Ray{p, direction}, cn);
+  if (h.shape < 0) return false;
+  return h.t < distance && (sc.shapes[h.shape].kind_flags & RT_SHAPE_SHADOW);
+}
+
+__device__ __forceinline__ V3 point_on_light(const RtLight& l, uint32_t li, uint32_t u, uint32_t v, uint32_t site,
+                                             const RenderParams& rp, uint32_t pixel, uint32_t path) {
+  float ju, jv;
+  if (rp.jitter_mode == RT_JITTER_COUNTER) {
+    uint32_t cell = u * l.vsteps + v;
+    ju = counter_jitter(rp.seed, pixel, path, li, cell, site, 0u);
+    jv = counter_jitter(rp.seed, pixel, path, li, cell, site, 1u);
+  } else {
+    ju = jv = rp.jitter_value;
+  }
+  V3 corner = v3(l.corner[0], l.corner[1], l.corner[2]);
+  V3 uvec = v3(l.uvec[0], l.uvec[1], l.uvec[2]), vvec = v3(l.vvec[0], l.vvec[1], l.vvec[2]);
+  return (corner + ((float)u + ju) * uvec) + ((float)v + jv) * vvec;
+}
+
+// One Phong sample (materials.rs:103-132 / :141-169). Returns false when the light is behind.
+__device__ __forceinline__ bool phong_sample(V3 light_pos, V3 pt, V3 eyev, V3 normalv, V3 effective, V3 lcol,
+                                             float mdiffuse, float mspecular, float shininess, V3& diffuse,
+                                             V3& specular) {
+  V3 lightv = normalize(light_pos - pt);
+  float light_dot_normal = dot(lightv, normalv);
+  if (!(light_dot_normal >= 0.f)) return false;
+  diffuse = light_dot_normal * (mdiffuse * effective);
+  V3 reflectv = reflect(-lightv, normalv);
+  float reflect_dot_eye = dot(reflectv, eyev);
+  if (reflect_dot_eye > 0.f) {
+    float factor = powf(reflect_dot_eye, shininess);
+    specular = factor * (mspecular * lcol);
+  } else {
+    specular = v3(0.f, 0.f, 0.f);
+  }
+  return true;
+}
+
+// The n1/n2 walk of Computations::prepare (intersections.rs:141-160) over the sorted,
+// de-duplicated list of every intersection up to the hit.
+__device__ inline void refractive_indices(const Scene& sc, const Ray& ray, const Hit& hit, float& n1, float& n2,
+                                          Counters& cn) {
+  float ts[RT_XS_CAP];
+  uint32_t ss[RT_XS_CAP];
+  CollectSink sink;
+  sink.ts = ts;
+  sink.ss = ss;
+  sink.n = 0;
+  sink.overflow = 0;
+  sink.tlimit = hit.t;
+  int ovf = 0;
+  world_intersect(sc, ray, sink, ovf);
+  cn.overflow += ovf + sink.overflow;
+  sort_entries(ts, ss, 0, sink.n);
+  int n = dedup_sorted(sc, ts, ss, 0, sink.n);
+  n1 = 1.f;
+  n2 = 1.f;
+  uint32_t containers[RT_XS_CAP];
+  int nc = 0;
+  uint32_t hit_vc = sc.shapes[hit.shape].vclass;
+  for (int i = 0; i < n; i++) {
+    uint32_t s = ss[i];
+    uint32_t vc = sc.shapes[s].vclass;
+    // `x == &intersection`: same t, equal shape value (u,v are functions of ray and shape value)
+    bool is_hit = of_eq(ts[i], hit.t) && vclass_eq(vc, hit_vc);
+    if (is_hit && nc > 0) n1 = sc.materials[sc.shapes[containers[nc - 1]].material].refractive_index;
+    int pos = -1;
+    for (int k = 0; k < nc; k++)
+      if (vclass_eq(sc.shapes[containers[k]].vclass, vc)) {
+        pos = k;
+        break;
+      }
+    if (pos >= 0) {
+      for (int k = pos; k + 1 < nc; k++) containers[k] = containers[k + 1];
+      nc--;
+    } else {
+      containers[nc++] = s;
+    }
+    if (is_hit && nc > 0) n2 = sc.materials[sc.shapes[containers[nc - 1]].material].refractive_index;
+  }
+}
+
+// World::color_at (world.rs:91-99) with the recursion of reflected_color / refracted_color
+// (world.rs:113-148) unrolled into an explicit stack of weighted rays (DESIGN.md "Integrator").
+struct PendingRay {
+  Ray ray;
+  float weight;
+  uint32_t remaining;
+  uint32_t path;
+};
+
+__device__ inline V3 color_at(const Scene& sc, const RenderParams& rp, Ray primary, uint32_t remaining0,
+                              uint32_t pixel, Counters& cn, Hit* primary_hit) {
+  PendingRay stack[RT_MAX_RAY_STACK];
+  int sp = 0;
+  stack[sp++] = PendingRay{primary, 1.f, remaining0, 1u};
+  V3 result = v3(0.f, 0.f, 0.f);
+  bool first = true;
+  const float nl = (float)sc.n_lights;
+  while (sp > 0) {
+    PendingRay pr = stack[--sp];
+    const Ray ray = pr.ray;
+    Hit hit = trace_closest(sc, ray, cn);
+    if (first) {
+      if (primary_hit) *primary_hit = hit;
+      first = false;
+    }
+    if (hit.shape < 0) continue;
+    // ---- Computations::prepare (intersections.rs:121-139) ----
+    const uint4* raw = reinterpret_cast<const uint4*>(sc.shapes + hit.shape);
+    uint4 w0 = raw[0], w1 = raw[1];
+    uint32_t kf = w0.x, sxf = w0.y, mat_id = w0.z, prim = w1.y;
+    int parent = (int)w0.w;
+    float smn = __uint_as_float(w1.z), smx = __uint_as_float(w1.w);
+    if ((kf & RT_SHAPE_KIND_MASK) == RT_SMOOTH_TRIANGLE && hit.u != hit.u) {
+      // hit came through a csg list, which does not carry (u,v): recompute them (same arithmetic)
+      Ray local = ray;
+      V3 p1, e1, e2;
+      load_tri(sc, prim, p1, e1, e2);
+      if (sxf) local = xf_ray(sc, sxf, ray);
+      float tt;
+      isect_triangle(local, p1, e1, e2, tt, hit.u, hit.v);
+    }
+    V3 point = ray.o + hit.t * ray.d;
+    V3 eyev = -ray.d;
+    V3 lp = world_to_object(sc, sxf, parent, point);
+    V3 ln = local_normal_at(sc, kf, smn, smx, prim, lp, hit.u, hit.v);
+    V3 normalv = normal_to_world(sc, sxf, parent, ln);
+    if (dot(normalv, eyev) < 0.f) normalv = -normalv;
+    V3 reflectv = reflect(ray.d, normalv);
+    V3 over_point = point + 1e-4f * normalv;
+    V3 under_point = point - 1e-4f * normalv;
+
+    const RtMaterial& m = sc.materials[mat_id];
+    const float m_ambient = m.ambient, m_diffuse = m.diffuse, m_specular = m.specular, m_shininess = m.shininess;
+    const float m_reflective = m.reflective, m_transparency = m.transparency;
+    V3 mcolor;
+    if (m.pattern >= 0) {  // pattern_at_shape at over_point (patterns.rs:79-91, world.rs:72)
+      const RtPattern& pat = sc.patterns[m.pattern];
+      V3 op = world_to_object(sc, sxf, parent, over_point);
+      V3 pp = xf_point(sc.xforms[pat.xform].m, op);
+      mcolor = pattern_at(sc, pat, pp);
+    } else {
+      mcolor = v3(m.color[0], m.color[1], m.color[2]);
+    }
+
+    // ---- World::shade_hit (world.rs:64-89): direct lighting, summed over lights ----
+    V3 surface_sum = v3(0.f, 0.f, 0.f);
+    for (uint32_t li = 0; li < sc.n_lights; li++) {
+      const RtLight& L = sc.lights[li];
+      V3 lcol = v3(L.intensity[0], L.intensity[1], L.intensity[2]);
+      V3 effective = mulc(mcolor, lcol);
+      V3 ambient = m_ambient * effective;
+      V3 surface;
+      if (L.kind == RT_LIGHT_POINT) {
+        V3 lpos = v3(L.position[0], L.position[1], L.position[2]);
+        float intensity = is_shadowed(sc, lpos, over_point, cn) ? 0.f : 1.f;  // lights.rs:50-56
+        V3 diffuse = v3(0.f, 0.f, 0.f), specular = v3(0.f, 0.f, 0.f);
+        phong_sample(lpos, over_point, eyev, normalv, effective, lcol, m_diffuse, m_specular, m_shininess, diffuse,
+                     specular);
+        surface = ambient + intensity * (diffuse + specular);  // materials.rs:134
+      } else {
+        // AreaLight::intensity_at (lights.rs:123-134)
+        float total = 0.f;
+        for (uint32_t u = 0; u < L.usteps; u++)
+          for (uint32_t v = 0; v < L.vsteps; v++) {
+            V3 lpos = point_on_light(L, li, u, v, 0u, rp, pixel, pr.path);
+            if (!is_shadowed(sc, lpos, over_point, cn)) total += 1.f;
+          }
+        float nb = (float)(L.usteps * L.vsteps);
+        float intensity = total / nb;
+        // materials.rs:136-175
+        V3 sum = v3(0.f, 0.f, 0.f);
+        for (uint32_t u = 0; u < L.usteps; u++)
+          for (uint32_t v = 0; v < L.vsteps; v++) {
+            V3 lpos = point_on_light(L, li, u, v, 1u, rp, pixel, pr.path);
+            V3 diffuse, specular;
+            if (phong_sample(lpos, over_point, eyev, normalv, effective, lcol, m_diffuse, m_specular, m_shininess,
+                             diffuse, specular))
+              sum = (sum + diffuse) + specular;
+          }
+        sum = (1.f / nb) * sum;
+        surface = ambient + intensity * sum;
+      }
+      surface_sum = surface_sum + surface;
+    }
+    result = result + pr.weight * surface_sum;
+
+    // ---- secondary rays (world.rs:78-86, :113-148); once per light in the reference (Q4) ----
+    if (pr.remaining == 0 || sc.n_lights == 0) continue;
+    bool want_reflect = m_reflective != 0.f;
+    bool want_refract = m_transparency != 0.f;
+    if (!want_reflect && !want_refract) continue;
+    float reflectance = 1.f, transmittance = 1.f;
+    float n1 = 1.f, n2 = 1.f;
+    if (want_refract) refractive_indices(sc, ray, hit, n1, n2, cn);
+    if (m_reflective > 0.f && m_transparency > 0.f) {  // Computations::schlick (intersections.rs:177-192)
+      float cosv = dot(eyev, normalv);
+      bool tir = false;
+      if (n1 > n2) {
+        float n = n1 / n2;
+        float sin2_t = (n * n) * (1.f - cosv * cosv);
+        if (sin2_t > 1.f)
+          tir = true;
+        else
+          cosv = __builtin_sqrtf(1.f - sin2_t);
+      }
+      if (tir) {
+        reflectance = 1.f;
+      } else {
+        float r = (n1 - n2) / (n1 + n2);
+        float r0 = r * r;
+        float x = 1.f - cosv;
+        float x2 = x * x;
+        float x4 = x2 * x2;
+        reflectance = r0 + (1.f - r0) * (x * x4);
+      }
+      transmittance = 1.f - reflectance;
+    }
+    if (want_refract) {  // refracted_color (world.rs:127-148); pushed first so reflection is traced first
+      float n_ratio = n1 / n2;
+      float cos_i = dot(eyev, normalv);
+      float sin2_t = (n_ratio * n_ratio) * (1.f - cos_i * cos_i);
+      if (!(sin2_t > 1.f)) {
+        float cos_t = __builtin_sqrtf(1.f - sin2_t);
+        V3 direction = (n_ratio * cos_i - cos_t) * normalv - n_ratio * eyev;
+        float w = pr.weight * nl * m_transparency * transmittance;
+        if (sp < RT_MAX_RAY_STACK) {
+          stack[sp++] = PendingRay{Ray{under_point, direction}, w, pr.remaining - 1u, pr.path * 2u + 1u};
+          cn.refract++;
+        } else {
+          cn.overflow++;
+        }
+      }
+    }
+    if (want_reflect) {  // reflected_color (world.rs:113-125)
+      float w = pr.weight * nl * m_reflective * reflectance;
+      if (sp < RT_MAX_RAY_STACK) {
+        stack[sp++] = PendingRay{Ray{over_point, reflectv}, w, pr.remaining - 1u, pr.path * 2u};
+        cn.reflect++;
+      } else {
+        cn.overflow++;
+      }
+    }
+  }
+  return result;
+}
+
+}  // namespace rtd

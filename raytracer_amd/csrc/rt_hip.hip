@@ -1,0 +1,506 @@
+// rt_hip.hip — librt_hip.so: the C ABI of include/rt_abi.h and the gfx950 render kernels.
+//
+// Build (see __graft_entry__.build): hipcc --offload-arch=gfx950 -O3 -ffp-contract=off
+//   -fhip-fp32-correctly-rounded-divide-sqrt -fPIC -shared
+// No FMA contraction and correctly rounded / and sqrt are REQUIRED for parity.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rt_device.h"
+
+using namespace rtd;
+
+namespace {
+
+struct PartInfo {
+  uint32_t tile_h, n_parts, part, rows;  // rows = number of local rows
+};
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ void flush_counters(const Counters& cn, unsigned long long* g) {
+  uint32_t a = wave_sum(cn.primary), b = wave_sum(cn.shadow), c = wave_sum(cn.reflect), d = wave_sum(cn.refract),
+           e = wave_sum(cn.overflow);
+  if ((threadIdx.x & 63) == 0) {
+    if (a) atomicAdd(g + 0, (unsigned long long)a);
+    if (b) atomicAdd(g + 1, (unsigned long long)b);
+    if (c) atomicAdd(g + 2, (unsigned long long)c);
+    if (d) atomicAdd(g + 3, (unsigned long long)d);
+    if (e) atomicAdd(g + 4, (unsigned long long)e);
+  }
+}
+
+// Camera::render (camera.rs:66-84): one lane per pixel, one wave per 8x8 pixel tile, four waves
+// per 16x16 block.  Rows are the interleaved scanline tiles of this part.
+__global__ __launch_bounds__(256) void k_render(Scene sc, RtCamera cam, RenderParams rp, PartInfo part,
+                                                float* __restrict__ out, uint8_t* __restrict__ mask,
+                                                int32_t* __restrict__ oid, float* __restrict__ ht,
+                                                unsigned long long* counters) {
+  const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const uint32_t px = blockIdx.x * 16u + (wave & 1u) * 8u + (lane & 7u);
+  const uint32_t ly = blockIdx.y * 16u + (wave >> 1) * 8u + (lane >> 3);
+  Counters cn = {0, 0, 0, 0, 0};
+  if (px < cam.hsize && ly < part.rows) {
+    const uint32_t py = (ly / part.tile_h) * (part.n_parts * part.tile_h) + part.part * part.tile_h + (ly % part.tile_h);
+    // Camera::ray_for_pixel (camera.rs:45-64)
+    float xoffset = ((float)px + 0.5f) * cam.pixel_size;
+    float yoffset = ((float)py + 0.5f) * cam.pixel_size;
+    float world_x = cam.half_width - xoffset;
+    float world_y = cam.half_height - yoffset;
+    V3 pixel = xf_point(cam.inv_transform, v3(world_x, world_y, -1.f));
+    V3 origin = xf_point(cam.inv_transform, v3(0.f, 0.f, 0.f));
+    V3 direction = normalize(pixel - origin);
+    cn.primary = 1;
+    Hit ph;
+    V3 col = color_at(sc, rp, Ray{origin, direction}, sc.recursion_limit, py * cam.hsize + px, cn, &ph);
+    size_t idx = (size_t)ly * cam.hsize + px;
+    out[3 * idx + 0] = col.x;
+    out[3 * idx + 1] = col.y;
+    out[3 * idx + 2] = col.z;
+    if (mask) mask[idx] = ph.shape >= 0 ? 1 : 0;
+    if (oid) oid[idx] = ph.shape;
+    if (ht) ht[idx] = ph.shape >= 0 ? ph.t : __builtin_nanf("");
+  }
+  flush_counters(cn, counters);
+}
+
+// World::color_at for caller-supplied rays (world.rs:91-99).
+__global__ __launch_bounds__(256) void k_color_at(Scene sc, RenderParams rp, const float* __restrict__ origins,
+                                                  const float* __restrict__ directions, uint32_t n,
+                                                  uint32_t remaining, float* __restrict__ out,
+                                                  float* __restrict__ hit_t, int32_t* __restrict__ hit_id,
+                                                  float* __restrict__ hit_uv, unsigned long long* counters) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  Counters cn = {0, 0, 0, 0, 0};
+  if (i < n) {
+    Ray r{v3(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]),
+          v3(directions[3 * i], directions[3 * i + 1], directions[3 * i + 2])};
+    cn.primary = 1;
+    Hit ph;
+    V3 col = color_at(sc, rp, r, remaining, i, cn, &ph);
+    if (out) {
+      out[3 * i] = col.x;
+      out[3 * i + 1] = col.y;
+      out[3 * i + 2] = col.z;
+    }
+    if (hit_t) hit_t[i] = ph.shape >= 0 ? ph.t : __builtin_nanf("");
+    if (hit_id) hit_id[i] = ph.shape;
+    if (hit_uv) {
+      hit_uv[2 * i] = ph.shape >= 0 && ph.u == ph.u ? ph.u : 0.f;
+      hit_uv[2 * i + 1] = ph.shape >= 0 && ph.v == ph.v ? ph.v : 0.f;
+    }
+  }
+  flush_counters(cn, counters);
+}
+
+}  // namespace
+
+// =========================================================================================
+// host side of the ABI
+// =========================================================================================
+struct RtContext {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  unsigned long long* d_counters = nullptr;
+  std::string error;
+};
+struct RtDeviceScene {
+  Scene sc{};
+  std::vector<void*> allocs;
+  RtContext* owner = nullptr;
+};
+
+namespace {
+
+int fail(RtContext* c, int code, const std::string& msg) {
+  if (c) c->error = msg;
+  return code;
+}
+#define HIP_TRY(ctx, expr)                                                                                  \
+  do {                                                                                                      \
+    hipError_t e_ = (expr);                                                                                 \
+    if (e_ != hipSuccess)                                                                                   \
+      return fail(ctx, e_ == hipErrorOutOfMemory ? RT_E_OOM : RT_E_DEVICE,                                  \
+                  std::string(#expr) + ": " + hipGetErrorString(e_));                                       \
+  } while (0)
+
+template <class T>
+int upload(RtContext* ctx, RtDeviceScene* ds, const T* src, size_t count, const T** dst) {
+  *dst = nullptr;
+  size_t bytes = (count ? count : 1) * sizeof(T);
+  void* p = nullptr;
+  HIP_TRY(ctx, hipMalloc(&p, bytes));
+  ds->allocs.push_back(p);
+  if (count) HIP_TRY(ctx, hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+  *dst = static_cast<const T*>(p);
+  return RT_OK;
+}
+
+// Reject anything that could make a kernel index out of bounds or overflow a fixed device stack.
+int validate_scene(RtContext* ctx, const RtScene* s) {
+  auto bad = [&](const char* what) { return fail(ctx, RT_E_SCENE, std::string("invalid scene: ") + what); };
+  if (s->abi_version != RT_ABI_VERSION) return fail(ctx, RT_E_ABI, "abi_version mismatch");
+  if (s->recursion_limit + 1 > RT_MAX_RAY_STACK) return bad("recursion_limit exceeds the device ray stack");
+  if (s->n_xforms < 1) return bad("xforms[0] (identity) missing");
+  if (s->n_loose_shapes > s->n_shapes) return bad("n_loose_shapes > n_shapes");
+  for (uint32_t i = 0; i < s->n_shapes; i++) {
+    const RtShape& sh = s->shapes[i];
+    uint32_t kind = sh.kind_flags & RT_SHAPE_KIND_MASK;
+    if (kind > RT_SMOOTH_TRIANGLE) return bad("shape kind");
+    if (sh.xform >= s->n_xforms) return bad("shape xform index");
+    if (sh.material >= s->n_materials) return bad("shape material index");
+    if (sh.parent >= (int32_t)s->n_nodes || sh.parent < -1) return bad("shape parent index");
+    if (kind >= RT_TRIANGLE && sh.prim >= s->n_tris) return bad("shape prim index");
+  }
+  std::vector<uint32_t> depth(s->n_nodes, 0);
+  for (uint32_t i = 0; i < s->n_nodes; i++) {
+    const RtNode& n = s->nodes[i];
+    if (n.xform >= s->n_xforms) return bad("node xform index");
+    if (n.skip <= i || n.skip > s->n_nodes) return bad("node skip pointer");
+    if (n.parent >= (int32_t)i || n.parent < -1) return bad("node parent index");
+    if ((uint64_t)n.first_shape + n.n_shapes > s->n_shapes) return bad("node shape range");
+    if ((n.flags & RT_NODE_ALL_TRIS) && (uint64_t)n.first_tri + n.n_shapes > s->n_tris) return bad("node tri range");
+    if (n.next_xf >= (int32_t)s->n_nodes || n.next_xf < -1) return bad("node next_xf");
+    if (n.next_xf >= 0 && (uint32_t)n.next_xf > i) return bad("node next_xf is not an ancestor");
+    if (n.next_xf >= 0 && s->nodes[n.next_xf].xform == 0) return bad("node next_xf has identity transform");
+    depth[i] = (n.parent >= 0 ? depth[n.parent] : 0) + (n.xform ? 1 : 0);
+    if (depth[i] > RT_MAX_XF_DEPTH) return bad("more nested group transforms than RT_MAX_XF_DEPTH");
+  }
+  for (uint32_t r = 0; r < s->n_csg_roots; r++) {
+    const RtCsgRoot& root = s->csg_roots[r];
+    if ((uint64_t)root.first + root.count > s->n_csg_nodes || root.count == 0) return bad("csg root range");
+    int sp = 0;
+    for (uint32_t k = root.first; k < root.first + root.count; k++) {
+      const RtCsgNode& n = s->csg_nodes[k];
+      if (n.op > RT_CSG_DIFFERENCE) return bad("csg op");
+      int nseg = 0;
+      if (n.flags & RT_CSG_LEFT_IS_SHAPE) {
+        if (n.left < 0 || (uint32_t)n.left >= s->n_shapes) return bad("csg left shape");
+      } else {
+        nseg++;
+        if (n.left_lo > n.left_hi || n.left_hi > s->n_shapes) return bad("csg left leaf range");
+      }
+      if (n.flags & RT_CSG_RIGHT_IS_SHAPE) {
+        if (n.right < 0 || (uint32_t)n.right >= s->n_shapes) return bad("csg right shape");
+      } else {
+        nseg++;
+      }
+      if (sp < nseg) return bad("csg nodes are not in post-order");
+      sp = sp - nseg + 1;
+      if (sp > RT_CSG_DEPTH) return bad("csg tree deeper than RT_CSG_DEPTH");
+    }
+    if (sp != 1) return bad("csg root does not reduce to one list");
+  }
+  for (uint32_t i = 0; i < s->n_materials; i++)
+    if (s->materials[i].pattern >= (int32_t)s->n_patterns || s->materials[i].pattern < -1) return bad("material pattern");
+  for (uint32_t i = 0; i < s->n_patterns; i++) {
+    const RtPattern& p = s->patterns[i];
+    if (p.kind > RT_PAT_CUBE_MAP || p.xform >= s->n_xforms) return bad("pattern");
+    int nuv = p.kind == RT_PAT_TEXTURE_MAP ? 1 : (p.kind == RT_PAT_CUBE_MAP ? 6 : 0);
+    for (int k = 0; k < nuv; k++)
+      if (p.uv[k] < 0 || p.uv[k] >= (int32_t)s->n_uvpatterns) return bad("pattern uv index");
+  }
+  for (uint32_t i = 0; i < s->n_uvpatterns; i++) {
+    const RtUvPattern& u = s->uvpatterns[i];
+    if (u.kind > RT_UV_IMAGE) return bad("uv pattern kind");
+    if (u.kind == RT_UV_IMAGE && (u.image < 0 || u.image >= (int32_t)s->n_images)) return bad("uv image index");
+  }
+  for (uint32_t i = 0; i < s->n_images; i++) {
+    const RtImage& im = s->images[i];
+    if (im.width == 0 || im.height == 0 || im.offset + (uint64_t)im.width * im.height * 3 > s->n_texels)
+      return bad("image texel range");
+  }
+  for (uint32_t i = 0; i < s->n_lights; i++)
+    if (s->lights[i].kind > RT_LIGHT_AREA) return bad("light kind");
+  return RT_OK;
+}
+
+PartInfo make_part(const RtCamera* cam, const RtRenderOptions* o) {
+  PartInfo p;
+  p.tile_h = (o && o->tile_h) ? o->tile_h : 1;
+  p.n_parts = (o && o->n_parts) ? o->n_parts : 1;
+  p.part = o ? o->part : 0;
+  uint32_t rows = 0;
+  for (uint32_t r = 0; r < cam->vsize; r++)
+    if ((r / p.tile_h) % p.n_parts == p.part) rows++;
+  p.rows = rows;
+  return p;
+}
+
+RenderParams make_params(const RtRenderOptions* o) {
+  RenderParams rp;
+  rp.jitter_mode = o ? o->jitter_mode : RT_JITTER_CONST;
+  rp.jitter_value = o ? o->jitter_value : 0.5f;
+  rp.seed = o ? o->seed : 0;
+  return rp;
+}
+
+int read_stats(RtContext* ctx, hipStream_t stream, RtStats* stats, double total_ms) {
+  unsigned long long h[8];
+  HIP_TRY(ctx, hipMemcpyAsync(h, ctx->d_counters, sizeof(h), hipMemcpyDeviceToHost, stream));
+  HIP_TRY(ctx, hipStreamSynchronize(stream));
+  float ms = 0.f;
+  HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  stats->primary = h[0];
+  stats->shadow = h[1];
+  stats->reflect = h[2];
+  stats->refract = h[3];
+  stats->overflow = h[4];
+  stats->kernel_ms = ms;
+  stats->total_ms = total_ms;
+  return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t rt_abi_version(void) { return RT_ABI_VERSION; }
+
+int rt_context_create(int device, RtContext** out) {
+  if (!out) return RT_E_ABI;
+  *out = nullptr;
+  RtContext* c = new RtContext();
+  c->device = device;
+  auto bail = [&](hipError_t e, const char* what) {
+    std::fprintf(stderr, "rt_context_create: %s: %s\n", what, hipGetErrorString(e));
+    delete c;
+    return RT_E_DEVICE;
+  };
+  hipError_t e;
+  if ((e = hipSetDevice(device)) != hipSuccess) return bail(e, "hipSetDevice");
+  if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
+  if ((e = hipEventCreate(&c->ev0)) != hipSuccess) return bail(e, "hipEventCreate");
+  if ((e = hipEventCreate(&c->ev1)) != hipSuccess) return bail(e, "hipEventCreate");
+  if ((e = hipMalloc((void**)&c->d_counters, 8 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc");
+  *out = c;
+  return RT_OK;
+}
+
+void rt_context_destroy(RtContext* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->d_counters) (void)hipFree(c->d_counters);
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+const char* rt_last_error(const RtContext* c) { return c ? c->error.c_str() : "null context"; }
+
+int rt_scene_create(RtContext* ctx, const RtScene* s, RtDeviceScene** out) {
+  if (!ctx || !s || !out) return RT_E_ABI;
+  *out = nullptr;
+  int rc = validate_scene(ctx, s);
+  if (rc != RT_OK) return rc;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  RtDeviceScene* ds = new RtDeviceScene();
+  ds->owner = ctx;
+  Scene& d = ds->sc;
+  const RtTriGeom* tg = nullptr;
+  const RtTriNormals* tn = nullptr;
+#define UP(field, src, count)                                 \
+  if ((rc = upload(ctx, ds, src, count, &field)) != RT_OK) {  \
+    rt_scene_destroy(ctx, ds);                                \
+    return rc;                                                \
+  }
+  UP(d.xforms, s->xforms, (size_t)s->n_xforms)
+  UP(d.shapes, s->shapes, (size_t)s->n_shapes)
+  UP(tg, s->tri_geom, (size_t)s->n_tris)
+  UP(tn, s->tri_normals, (size_t)s->n_tris)
+  UP(d.nodes, s->nodes, (size_t)s->n_nodes)
+  UP(d.csg_nodes, s->csg_nodes, (size_t)s->n_csg_nodes)
+  UP(d.csg_roots, s->csg_roots, (size_t)s->n_csg_roots)
+  UP(d.materials, s->materials, (size_t)s->n_materials)
+  UP(d.patterns, s->patterns, (size_t)s->n_patterns)
+  UP(d.uvpatterns, s->uvpatterns, (size_t)s->n_uvpatterns)
+  UP(d.images, s->images, (size_t)s->n_images)
+  UP(d.texels, s->texels, (size_t)s->n_texels)
+  UP(d.lights, s->lights, (size_t)s->n_lights)
+#undef UP
+  d.tri_geom = reinterpret_cast<const float4*>(tg);
+  d.tri_normals = reinterpret_cast<const float4*>(tn);
+  d.n_shapes = s->n_shapes;
+  d.n_nodes = s->n_nodes;
+  d.n_csg_roots = s->n_csg_roots;
+  d.n_lights = s->n_lights;
+  d.n_loose = s->n_loose_shapes;
+  d.recursion_limit = s->recursion_limit;
+  d.flags = 0;
+  hipError_t e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) {
+    rt_scene_destroy(ctx, ds);
+    return fail(ctx, RT_E_DEVICE, std::string("scene upload: ") + hipGetErrorString(e));
+  }
+  *out = ds;
+  return RT_OK;
+}
+
+void rt_scene_destroy(RtContext* ctx, RtDeviceScene* ds) {
+  if (!ds) return;
+  if (ctx) (void)hipSetDevice(ctx->device);
+  for (void* p : ds->allocs) (void)hipFree(p);
+  delete ds;
+}
+
+uint32_t rt_part_rows(const RtCamera* cam, const RtRenderOptions* o) { return cam ? make_part(cam, o).rows : 0; }
+
+int rt_render_device(RtContext* ctx, const RtDeviceScene* ds, const RtCamera* cam, const RtRenderOptions* opts,
+                     float* d_out_rgb, RtAux* d_aux, void* stream_, RtStats* stats) {
+  if (!ctx || !ds || !cam || !d_out_rgb) return RT_E_ABI;
+  if (ds->owner != ctx) return fail(ctx, RT_E_ABI, "scene belongs to another context");
+  if (cam->hsize == 0 || cam->vsize == 0) return fail(ctx, RT_E_ABI, "empty camera");
+  PartInfo part = make_part(cam, opts);
+  if (part.part >= part.n_parts) return fail(ctx, RT_E_ABI, "part >= n_parts");
+  auto t0 = std::chrono::steady_clock::now();
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t stream = stream_ ? (hipStream_t)stream_ : ctx->stream;
+  Scene sc = ds->sc;
+  sc.flags = opts ? opts->flags : 0;
+  RenderParams rp = make_params(opts);
+  HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 8 * sizeof(unsigned long long), stream));
+  if (part.rows > 0) {
+    dim3 grid((cam->hsize + 15) / 16, (part.rows + 15) / 16);
+    HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
+    hipLaunchKernelGGL(k_render, grid, dim3(256), 0, stream, sc, *cam, rp, part, d_out_rgb,
+                       d_aux ? d_aux->hit_mask : nullptr, d_aux ? d_aux->object_id : nullptr,
+                       d_aux ? d_aux->hit_t : nullptr, ctx->d_counters);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->ev1, stream));
+  } else {
+    HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev1, stream));
+  }
+  if (stats) {
+    HIP_TRY(ctx, hipStreamSynchronize(stream));
+    double total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    int rc = read_stats(ctx, stream, stats, total);
+    if (rc != RT_OK) return rc;
+    if (stats->overflow) return fail(ctx, RT_E_OVERFLOW, "per-ray intersection list overflow");
+  }
+  return RT_OK;
+}
+
+int rt_render(RtContext* ctx, const RtDeviceScene* ds, const RtCamera* cam, const RtRenderOptions* opts,
+              float* out_rgb, RtAux* aux, RtStats* stats) {
+  if (!ctx || !ds || !cam || !out_rgb) return RT_E_ABI;
+  auto t0 = std::chrono::steady_clock::now();
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  PartInfo part = make_part(cam, opts);
+  size_t npix = (size_t)part.rows * cam->hsize;
+  float* d_out = nullptr;
+  uint8_t* d_mask = nullptr;
+  int32_t* d_oid = nullptr;
+  float* d_ht = nullptr;
+  int rc = RT_OK;
+  RtStats local{};
+  RtAux d_aux{};
+  auto cleanup = [&]() {
+    if (d_out) (void)hipFree(d_out);
+    if (d_mask) (void)hipFree(d_mask);
+    if (d_oid) (void)hipFree(d_oid);
+    if (d_ht) (void)hipFree(d_ht);
+  };
+#define TRY_CLEAN(expr)                                                                      \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess) {                                                                  \
+      cleanup();                                                                             \
+      return fail(ctx, e_ == hipErrorOutOfMemory ? RT_E_OOM : RT_E_DEVICE,                   \
+                  std::string(#expr) + ": " + hipGetErrorString(e_));                        \
+    }                                                                                        \
+  } while (0)
+  TRY_CLEAN(hipMalloc((void**)&d_out, (npix ? npix : 1) * 3 * sizeof(float)));
+  if (aux && aux->hit_mask) TRY_CLEAN(hipMalloc((void**)&d_mask, npix ? npix : 1));
+  if (aux && aux->object_id) TRY_CLEAN(hipMalloc((void**)&d_oid, (npix ? npix : 1) * sizeof(int32_t)));
+  if (aux && aux->hit_t) TRY_CLEAN(hipMalloc((void**)&d_ht, (npix ? npix : 1) * sizeof(float)));
+  d_aux.hit_mask = d_mask;
+  d_aux.object_id = d_oid;
+  d_aux.hit_t = d_ht;
+  rc = rt_render_device(ctx, ds, cam, opts, d_out, aux ? &d_aux : nullptr, nullptr, &local);
+  if (rc != RT_OK && rc != RT_E_OVERFLOW) {
+    cleanup();
+    return rc;
+  }
+  TRY_CLEAN(hipMemcpy(out_rgb, d_out, npix * 3 * sizeof(float), hipMemcpyDeviceToHost));
+  if (d_mask) TRY_CLEAN(hipMemcpy(aux->hit_mask, d_mask, npix, hipMemcpyDeviceToHost));
+  if (d_oid) TRY_CLEAN(hipMemcpy(aux->object_id, d_oid, npix * sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (d_ht) TRY_CLEAN(hipMemcpy(aux->hit_t, d_ht, npix * sizeof(float), hipMemcpyDeviceToHost));
+  cleanup();
+#undef TRY_CLEAN
+  if (stats) {
+    *stats = local;
+    stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  }
+  return rc;
+}
+
+int rt_color_at(RtContext* ctx, const RtDeviceScene* ds, const RtRenderOptions* opts, const float* origins,
+                const float* directions, uint32_t n, uint32_t remaining, float* out_rgb, float* hit_t,
+                int32_t* hit_id, float* hit_uv, RtStats* stats) {
+  if (!ctx || !ds || (n && (!origins || !directions))) return RT_E_ABI;
+  if (ds->owner != ctx) return fail(ctx, RT_E_ABI, "scene belongs to another context");
+  if (remaining + 1 > RT_MAX_RAY_STACK) return fail(ctx, RT_E_SCENE, "remaining exceeds the device ray stack");
+  auto t0 = std::chrono::steady_clock::now();
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (n == 0) return RT_OK;
+  float *d_o = nullptr, *d_d = nullptr, *d_rgb = nullptr, *d_t = nullptr, *d_uv = nullptr;
+  int32_t* d_id = nullptr;
+  auto cleanup = [&]() {
+    for (void* p : {(void*)d_o, (void*)d_d, (void*)d_rgb, (void*)d_t, (void*)d_uv, (void*)d_id})
+      if (p) (void)hipFree(p);
+  };
+#define TRY_CLEAN(expr)                                                                      \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess) {                                                                  \
+      cleanup();                                                                             \
+      return fail(ctx, e_ == hipErrorOutOfMemory ? RT_E_OOM : RT_E_DEVICE,                   \
+                  std::string(#expr) + ": " + hipGetErrorString(e_));                        \
+    }                                                                                        \
+  } while (0)
+  size_t n3 = (size_t)n * 3 * sizeof(float);
+  TRY_CLEAN(hipMalloc((void**)&d_o, n3));
+  TRY_CLEAN(hipMalloc((void**)&d_d, n3));
+  TRY_CLEAN(hipMalloc((void**)&d_rgb, n3));
+  TRY_CLEAN(hipMalloc((void**)&d_t, (size_t)n * sizeof(float)));
+  TRY_CLEAN(hipMalloc((void**)&d_uv, (size_t)n * 2 * sizeof(float)));
+  TRY_CLEAN(hipMalloc((void**)&d_id, (size_t)n * sizeof(int32_t)));
+  TRY_CLEAN(hipMemcpyAsync(d_o, origins, n3, hipMemcpyHostToDevice, ctx->stream));
+  TRY_CLEAN(hipMemcpyAsync(d_d, directions, n3, hipMemcpyHostToDevice, ctx->stream));
+  TRY_CLEAN(hipMemsetAsync(ctx->d_counters, 0, 8 * sizeof(unsigned long long), ctx->stream));
+  Scene sc = ds->sc;
+  sc.flags = opts ? opts->flags : 0;
+  RenderParams rp = make_params(opts);
+  TRY_CLEAN(hipEventRecord(ctx->ev0, ctx->stream));
+  hipLaunchKernelGGL(k_color_at, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, sc, rp, d_o, d_d, n, remaining,
+                     d_rgb, d_t, d_id, d_uv, ctx->d_counters);
+  TRY_CLEAN(hipGetLastError());
+  TRY_CLEAN(hipEventRecord(ctx->ev1, ctx->stream));
+  TRY_CLEAN(hipStreamSynchronize(ctx->stream));
+  if (out_rgb) TRY_CLEAN(hipMemcpy(out_rgb, d_rgb, n3, hipMemcpyDeviceToHost));
+  if (hit_t) TRY_CLEAN(hipMemcpy(hit_t, d_t, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+  if (hit_id) TRY_CLEAN(hipMemcpy(hit_id, d_id, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (hit_uv) TRY_CLEAN(hipMemcpy(hit_uv, d_uv, (size_t)n * 2 * sizeof(float), hipMemcpyDeviceToHost));
+  RtStats local{};
+  double total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  int rc = read_stats(ctx, ctx->stream, &local, total);
+  cleanup();
+#undef TRY_CLEAN
+  if (rc != RT_OK) return rc;
+  if (stats) *stats = local;
+  if (local.overflow) return fail(ctx, RT_E_OVERFLOW, "per-ray intersection list overflow");
+  return RT_OK;
+}
+
+}  // extern "C"
