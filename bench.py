@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""bench.py — Mrays/s of the MI355X render path on the headline workload.
+
+A "step" is one full frame of the workload: every rank renders its interleaved scanline tiles
+with the HIP kernels (scene already resident in HBM), then (N > 1) the canvases are all-gathered
+over RCCL and de-interleaved.  value = rays of the whole frame / mean step time, in Mrays/s, where a
+ray is one World::intersect-equivalent query (primary + shadow + reflect + refract).
+
+Default workload: samples/scenes/dragons.yaml at 3840x2160 (BASELINE.json: "frame time 4K dragons")
+with the deterministic synthetic stand-in for dragon.obj (the real file is not redistributable
+here; set RT_ASSETS=/dir/with/dragon.obj to use it).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from raytracer_amd import abi, host, synth, tiles  # noqa: E402
+from raytracer_amd.obj import parse_obj  # noqa: E402
+from raytracer_amd.scene import Scene  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+
+
+def load_workload(name: str):
+    meshes, label = {}, ""
+    if name == "dragons":
+        assets = os.environ.get("RT_ASSETS", "")
+        real = os.path.join(assets, "dragon.obj") if assets else ""
+        if real and os.path.exists(real):
+            mesh, label = parse_obj(real), "real dragon.obj"
+        else:
+            mesh, label = synth.synth_dragon(), "synthetic dragon"
+        label += " sha256=" + synth.mesh_sha256(mesh)[:16]
+        meshes["dragon.obj"] = mesh
+    objs = [os.path.join(ROOT, "scenes", "obj", f) for f in ("space_ship.obj", "teapot_low.obj")]
+    scene = Scene.from_file(os.path.join(ROOT, "scenes", f"{name}.yaml"), obj_files=objs, meshes=meshes)
+    return scene, label
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="dragons")
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--tile-h", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-pixels", type=int, default=130000)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: there is no CPU render path in the product")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    scene, mesh_label = load_workload(args.workload)
+    cam = scene.camera(args.width, args.height)
+    t0 = time.time()
+    hw = scene.build(host.new_world(local_rank))
+    ctx, dscene = hw.device_scene()
+    setup_s = time.time() - t0
+    lib = host.hip_lib()
+    rcam = hw.rt_camera(cam)
+    opts = abi.RtRenderOptions(abi.RT_JITTER_COUNTER, 0.5, 1, args.tile_h, world, rank, 0)
+    rows = int(lib.rt_part_rows(C.byref(rcam), C.byref(opts)))
+    max_rows = tiles.max_part_rows(cam.vsize, args.tile_h, world)
+    local = torch.zeros((max_rows, cam.hsize, 3), dtype=torch.float32, device=dev)
+    gathered = torch.empty((world, max_rows, cam.hsize, 3), dtype=torch.float32, device=dev) if world > 1 else None
+    perm = torch.from_numpy(tiles.row_permutation(cam.vsize, args.tile_h, world)).to(dev) if world > 1 else None
+    stream = torch.cuda.current_stream(dev)
+
+    def check(rc, what):
+        if rc != abi.RT_OK:
+            raise RuntimeError(f"{what} failed ({rc}): {lib.rt_last_error(ctx).decode()}")
+
+    def step():
+        check(lib.rt_render_device(ctx, dscene, C.byref(rcam), C.byref(opts), local.data_ptr(), None,
+                                   C.c_void_p(stream.cuda_stream), None), "rt_render_device")
+        if world > 1:
+            return tiles.gather_canvas(local, cam.vsize, args.tile_h, perm=perm, gathered=gathered)
+        return local
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    # rays of this rank's part (deterministic) + work counters, from one instrumented launch
+    copts = abi.RtRenderOptions(abi.RT_JITTER_COUNTER, 0.5, 1, args.tile_h, world, rank, abi.RT_RENDER_COUNT_WORK)
+    cst = abi.RtStats()
+    check(lib.rt_render_device(ctx, dscene, C.byref(rcam), C.byref(copts), local.data_ptr(), None,
+                               C.c_void_p(stream.cuda_stream), C.byref(cst)), "rt_render_device(count)")
+    my_rays = cst.primary + cst.shadow + cst.reflect + cst.refract
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        canvas = step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    tot = torch.tensor([elapsed, float(my_rays)], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = tot.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        elapsed = float(tmax[0])
+    total_rays = float(tot[1])
+    ms_per_step = elapsed / args.steps * 1e3
+    value = total_rays / (ms_per_step * 1e-3) / 1e6
+
+    # dominant kernel: average launch duration from HIP events on the render stream
+    kms = []
+    st = abi.RtStats()
+    for _ in range(max(3, args.steps)):
+        check(lib.rt_render_device(ctx, dscene, C.byref(rcam), C.byref(opts), local.data_ptr(), None,
+                                   C.c_void_p(stream.cuda_stream), C.byref(st)), "rt_render_device(stats)")
+        kms.append(st.kernel_ms)
+    kernel_ms = float(np.mean(kms))
+    # algorithmic bytes of one launch (SURVEY.md §8d / DESIGN.md "Measurement")
+    alg_bytes = (cst.node_visits * 32 + cst.tri_tests * 36 + cst.shape_tests * 32 + cst.shaded_hits * 36
+                 + cst.node_xforms * 48 + rows * cam.hsize * 12)
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "kernel": "k_render", "kernel_ms": round(kernel_ms, 3), "algorithmic_bytes": int(alg_bytes),
+                "counters": {"node_visits": cst.node_visits, "tri_tests": cst.tri_tests,
+                             "shape_tests": cst.shape_tests, "shaded_hits": cst.shaded_hits,
+                             "node_xforms": cst.node_xforms}}
+
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle
+        from raytracer_amd.builder import JITTER_COUNTER, RenderOptions
+        stepn = max(1, int(round((cam.hsize * cam.vsize / args.cpu_sample_pixels) ** 0.5)))
+        threads = min(16, os.cpu_count() or 1)
+        ow = scene.build(oracle.new_world())
+        ro = RenderOptions(jitter_mode=JITTER_COUNTER, seed=1, threads=threads, row_step=stepn, col_step=stepn)
+        r = ow.render(cam, ro)
+        rays = r.stats["primary"] + r.stats["shadow"] + r.stats["reflect"] + r.stats["refract"]
+        cpu_baseline = {"value": round(rays / r.stats["seconds"] / 1e6, 4), "unit": "Mrays/s", "cores": threads,
+                        "kind": "port",
+                        "sample": f"every {stepn}th row and column of the same frame "
+                                  f"({r.stats['primary']} primary rays, {r.stats['seconds']:.1f} s); C++ restatement "
+                                  f"of the reference (oracle/), not the Rust reference itself"}
+
+    if rank == 0:
+        out = {
+            "metric": "Mrays/s (primary+shadow+secondary)", "value": round(value, 2), "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic" if "synthetic" in mesh_label or args.workload != "dragons" else "real",
+            "config": {"workload": f"{args.workload}.yaml {cam.hsize}x{cam.vsize} recursion_limit 4 {mesh_label}".strip(),
+                       "tile_h": args.tile_h, "parts": world, "rays_per_frame": int(total_rays),
+                       "frame_ms": round(ms_per_step, 3), "scene_setup_s": round(setup_s, 1)},
+            "roofline": roofline, "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -209,7 +209,8 @@ typedef struct {
   uint32_t tile_h, n_parts, part;
   uint32_t flags; /* RT_RENDER_* */
 } RtRenderOptions;
-#define RT_RENDER_NO_PRUNE 0x1u /* visit every node the reference visits (no distance pruning) */
+#define RT_RENDER_NO_PRUNE 0x1u   /* visit every node the reference visits (no distance pruning) */
+#define RT_RENDER_COUNT_WORK 0x2u /* instrumented kernel: also fill the work counters of RtStats (slower) */
 
 /* Optional per-pixel side outputs of the PRIMARY ray, same compaction as the image. */
 typedef struct {
@@ -222,6 +223,9 @@ typedef struct {
 typedef struct {
   uint64_t primary, shadow, reflect, refract;
   uint64_t overflow;   /* intersection-list overflows (must be 0 for a valid image) */
+  /* work counters, only with RT_RENDER_COUNT_WORK (else 0): what the roofline's algorithmic
+   * bytes/flops are computed from (DESIGN.md "Measurement") */
+  uint64_t node_visits, tri_tests, shape_tests, shaded_hits, node_xforms;
   double kernel_ms;    /* device time of the render kernel(s), HIP events on the render stream */
   double total_ms;     /* wall time of the call */
 } RtStats;

@@ -12,7 +12,7 @@ RT_VCLASS_NEVER = 0xFFFFFFFF
 RT_NODE_ALL_TRIS, RT_NODE_PRUNABLE = 1, 2
 RT_CSG_LEFT_IS_SHAPE, RT_CSG_RIGHT_IS_SHAPE = 1, 2
 RT_JITTER_CONST, RT_JITTER_COUNTER = 0, 1
-RT_RENDER_NO_PRUNE = 1
+RT_RENDER_NO_PRUNE, RT_RENDER_COUNT_WORK = 1, 2
 
 # numpy dtypes of the device records (must match the C structs byte for byte)
 XFORM = np.dtype([("m", "<f4", 12)])
@@ -78,7 +78,9 @@ class RtAux(C.Structure):
 
 class RtStats(C.Structure):
     _fields_ = [("primary", C.c_uint64), ("shadow", C.c_uint64), ("reflect", C.c_uint64), ("refract", C.c_uint64),
-                ("overflow", C.c_uint64), ("kernel_ms", C.c_double), ("total_ms", C.c_double)]
+                ("overflow", C.c_uint64), ("node_visits", C.c_uint64), ("tri_tests", C.c_uint64),
+                ("shape_tests", C.c_uint64), ("shaded_hits", C.c_uint64), ("node_xforms", C.c_uint64),
+                ("kernel_ms", C.c_double), ("total_ms", C.c_double)]
 
 
 EXPORTS = ["rt_abi_version", "rt_context_create", "rt_context_destroy", "rt_last_error", "rt_scene_create",

@@ -48,6 +48,12 @@ __device__ __forceinline__ bool of_eq(float a, float b) { return (a == b) || ((a
 __device__ __forceinline__ float of_max(float a, float b) { return of_gt(a, b) ? a : b; }
 __device__ __forceinline__ float of_min(float a, float b) { return of_gt(a, b) ? b : a; }
 
+struct Counters {
+  uint32_t primary, shadow, reflect, refract, overflow;
+  // work counters (only maintained by the COUNT instantiations; bench roofline)
+  uint32_t node_visits, tri_tests, shape_tests, shaded, xforms;
+};
+
 struct Scene {
   const RtXform* xforms;
   const RtShape* shapes;
@@ -471,8 +477,9 @@ __device__ inline void csg_eval(const Scene& sc, RtCsgRoot root, const Ray& ray,
 // re-expressed in a group's space when the group has a non-identity transform (groups.rs:127-133)
 // and restored when the walk leaves that subtree.
 // ---------------------------------------------------------------------------------------
-template <class Sink>
-__device__ inline void world_intersect(const Scene& sc, const Ray& ray, Sink& sink, int& csg_overflow) {
+template <bool COUNT, class Sink>
+__device__ inline void world_intersect(const Scene& sc, const Ray& ray, Sink& sink, Counters& cn) {
+  int csg_overflow = 0;
   // csgs first (world.rs:45-49)
   if (sc.n_csg_roots) {
     CsgList L;
@@ -483,6 +490,7 @@ __device__ inline void world_intersect(const Scene& sc, const Ray& ray, Sink& si
     }
     csg_overflow |= L.overflow;
   }
+  cn.overflow += csg_overflow;
   // groups (world.rs:51-54)
   {
     Ray saved[RT_MAX_XF_DEPTH];
@@ -496,6 +504,8 @@ __device__ inline void world_intersect(const Scene& sc, const Ray& ray, Sink& si
       const uint4* raw = reinterpret_cast<const uint4*>(sc.nodes + i);
       uint4 w0 = raw[0], w1 = raw[1], w2 = raw[2], w3 = raw[3];
       uint32_t xform = w0.w, flags = w1.w, skip = w2.z;
+      if (COUNT) cn.node_visits++;
+      if (COUNT && xform) cn.xforms++;
       if (xform) {
         saved[rs] = cur;
         restore_at[rs] = skip;
@@ -525,6 +535,7 @@ __device__ inline void world_intersect(const Scene& sc, const Ray& ray, Sink& si
       uint32_t first_shape = w2.x, n_shapes = w2.y;
       if (flags & RT_NODE_ALL_TRIS) {
         uint32_t first_tri = w3.x;
+        if (COUNT) cn.tri_tests += n_shapes;
         for (uint32_t k = 0; k < n_shapes; k++) {
           V3 p1, e1, e2;
           load_tri(sc, first_tri + k, p1, e1, e2);
@@ -532,12 +543,14 @@ __device__ inline void world_intersect(const Scene& sc, const Ray& ray, Sink& si
           if (isect_triangle(cur, p1, e1, e2, t, u, v)) sink.add(t, first_shape + k, u, v);
         }
       } else {
+        if (COUNT) cn.shape_tests += n_shapes;
         for (uint32_t k = 0; k < n_shapes; k++) shape_intersect(sc, first_shape + k, cur, sink);
       }
       i = i + 1;
     }
   }
   // loose shapes (world.rs:56-59): the last n_loose entries of shapes[]
+  if (COUNT) cn.shape_tests += sc.n_loose;
   for (uint32_t k = sc.n_shapes - sc.n_loose; k < sc.n_shapes; k++) shape_intersect(sc, k, ray, sink);
 }
 
@@ -766,32 +779,28 @@ struct RenderParams {
   float jitter_value;
   uint64_t seed;
 };
-struct Counters {
-  uint32_t primary, shadow, reflect, refract, overflow;
-};
-
 struct Hit {
   float t, u, v;
   int shape;
 };
 
 // Intersections::hit() of World::intersect(ray).
+template <bool COUNT>
 __device__ inline Hit trace_closest(const Scene& sc, const Ray& ray, Counters& cn) {
   ClosestSink sink;
   sink.init();
-  int ovf = 0;
-  world_intersect(sc, ray, sink, ovf);
-  cn.overflow += ovf;
+  world_intersect<COUNT>(sc, ray, sink, cn);
   return Hit{sink.t, sink.u, sink.v, sink.shape};
 }
 
 // World::is_shadowed (world.rs:101-111): closest-hit semantics.
+template <bool COUNT>
 __device__ inline bool is_shadowed(const Scene& sc, V3 light_position, V3 p, Counters& cn) {
   V3 v = light_position - p;
   float distance = magnitude(v);
   V3 direction = v / distance;
   cn.shadow++;
-  Hit h = trace_closest(sc, Ray{p, direction}, cn);
+  Hit h = trace_closest<COUNT>(sc, Ray{p, direction}, cn);
   if (h.shape < 0) return false;
   return h.t < distance && (sc.shapes[h.shape].kind_flags & RT_SHAPE_SHADOW);
 }
@@ -832,6 +841,7 @@ __device__ __forceinline__ bool phong_sample(V3 light_pos, V3 pt, V3 eyev, V3 no
 
 // The n1/n2 walk of Computations::prepare (intersections.rs:141-160) over the sorted,
 // de-duplicated list of every intersection up to the hit.
+template <bool COUNT>
 __device__ inline void refractive_indices(const Scene& sc, const Ray& ray, const Hit& hit, float& n1, float& n2,
                                           Counters& cn) {
   float ts[RT_XS_CAP];
@@ -842,9 +852,8 @@ __device__ inline void refractive_indices(const Scene& sc, const Ray& ray, const
   sink.n = 0;
   sink.overflow = 0;
   sink.tlimit = hit.t;
-  int ovf = 0;
-  world_intersect(sc, ray, sink, ovf);
-  cn.overflow += ovf + sink.overflow;
+  world_intersect<COUNT>(sc, ray, sink, cn);
+  cn.overflow += sink.overflow;
   sort_entries(ts, ss, 0, sink.n);
   int n = dedup_sorted(sc, ts, ss, 0, sink.n);
   n1 = 1.f;
@@ -883,6 +892,7 @@ struct PendingRay {
   uint32_t path;
 };
 
+template <bool COUNT>
 __device__ inline V3 color_at(const Scene& sc, const RenderParams& rp, Ray primary, uint32_t remaining0,
                               uint32_t pixel, Counters& cn, Hit* primary_hit) {
   PendingRay stack[RT_MAX_RAY_STACK];
@@ -894,12 +904,13 @@ __device__ inline V3 color_at(const Scene& sc, const RenderParams& rp, Ray prima
   while (sp > 0) {
     PendingRay pr = stack[--sp];
     const Ray ray = pr.ray;
-    Hit hit = trace_closest(sc, ray, cn);
+    Hit hit = trace_closest<COUNT>(sc, ray, cn);
     if (first) {
       if (primary_hit) *primary_hit = hit;
       first = false;
     }
     if (hit.shape < 0) continue;
+    if (COUNT) cn.shaded++;
     // ---- Computations::prepare (intersections.rs:121-139) ----
     const uint4* raw = reinterpret_cast<const uint4*>(sc.shapes + hit.shape);
     uint4 w0 = raw[0], w1 = raw[1];
@@ -948,7 +959,7 @@ __device__ inline V3 color_at(const Scene& sc, const RenderParams& rp, Ray prima
       V3 surface;
       if (L.kind == RT_LIGHT_POINT) {
         V3 lpos = v3(L.position[0], L.position[1], L.position[2]);
-        float intensity = is_shadowed(sc, lpos, over_point, cn) ? 0.f : 1.f;  // lights.rs:50-56
+        float intensity = is_shadowed<COUNT>(sc, lpos, over_point, cn) ? 0.f : 1.f;  // lights.rs:50-56
         V3 diffuse = v3(0.f, 0.f, 0.f), specular = v3(0.f, 0.f, 0.f);
         phong_sample(lpos, over_point, eyev, normalv, effective, lcol, m_diffuse, m_specular, m_shininess, diffuse,
                      specular);
@@ -959,7 +970,7 @@ __device__ inline V3 color_at(const Scene& sc, const RenderParams& rp, Ray prima
         for (uint32_t u = 0; u < L.usteps; u++)
           for (uint32_t v = 0; v < L.vsteps; v++) {
             V3 lpos = point_on_light(L, li, u, v, 0u, rp, pixel, pr.path);
-            if (!is_shadowed(sc, lpos, over_point, cn)) total += 1.f;
+            if (!is_shadowed<COUNT>(sc, lpos, over_point, cn)) total += 1.f;
           }
         float nb = (float)(L.usteps * L.vsteps);
         float intensity = total / nb;
@@ -987,7 +998,7 @@ __device__ inline V3 color_at(const Scene& sc, const RenderParams& rp, Ray prima
     if (!want_reflect && !want_refract) continue;
     float reflectance = 1.f, transmittance = 1.f;
     float n1 = 1.f, n2 = 1.f;
-    if (want_refract) refractive_indices(sc, ray, hit, n1, n2, cn);
+    if (want_refract) refractive_indices<COUNT>(sc, ray, hit, n1, n2, cn);
     if (m_reflective > 0.f && m_transparency > 0.f) {  // Computations::schlick (intersections.rs:177-192)
       float cosv = dot(eyev, normalv);
       bool tir = false;

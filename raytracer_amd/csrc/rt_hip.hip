@@ -17,6 +17,8 @@ using namespace rtd;
 
 namespace {
 
+#define RT_N_COUNTERS 16
+
 struct PartInfo {
   uint32_t tile_h, n_parts, part, rows;  // rows = number of local rows
 };
@@ -29,7 +31,14 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 __device__ __forceinline__ void flush_counters(const Counters& cn, unsigned long long* g) {
   uint32_t a = wave_sum(cn.primary), b = wave_sum(cn.shadow), c = wave_sum(cn.reflect), d = wave_sum(cn.refract),
            e = wave_sum(cn.overflow);
+  uint32_t w0 = wave_sum(cn.node_visits), w1 = wave_sum(cn.tri_tests), w2 = wave_sum(cn.shape_tests),
+           w3 = wave_sum(cn.shaded), w4 = wave_sum(cn.xforms);
   if ((threadIdx.x & 63) == 0) {
+    if (w0) atomicAdd(g + 5, (unsigned long long)w0);
+    if (w1) atomicAdd(g + 6, (unsigned long long)w1);
+    if (w2) atomicAdd(g + 7, (unsigned long long)w2);
+    if (w3) atomicAdd(g + 8, (unsigned long long)w3);
+    if (w4) atomicAdd(g + 9, (unsigned long long)w4);
     if (a) atomicAdd(g + 0, (unsigned long long)a);
     if (b) atomicAdd(g + 1, (unsigned long long)b);
     if (c) atomicAdd(g + 2, (unsigned long long)c);
@@ -40,6 +49,7 @@ __device__ __forceinline__ void flush_counters(const Counters& cn, unsigned long
 
 // Camera::render (camera.rs:66-84): one lane per pixel, one wave per 8x8 pixel tile, four waves
 // per 16x16 block.  Rows are the interleaved scanline tiles of this part.
+template <bool COUNT>
 __global__ __launch_bounds__(256) void k_render(Scene sc, RtCamera cam, RenderParams rp, PartInfo part,
                                                 float* __restrict__ out, uint8_t* __restrict__ mask,
                                                 int32_t* __restrict__ oid, float* __restrict__ ht,
@@ -47,7 +57,7 @@ __global__ __launch_bounds__(256) void k_render(Scene sc, RtCamera cam, RenderPa
   const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const uint32_t px = blockIdx.x * 16u + (wave & 1u) * 8u + (lane & 7u);
   const uint32_t ly = blockIdx.y * 16u + (wave >> 1) * 8u + (lane >> 3);
-  Counters cn = {0, 0, 0, 0, 0};
+  Counters cn = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (px < cam.hsize && ly < part.rows) {
     const uint32_t py = (ly / part.tile_h) * (part.n_parts * part.tile_h) + part.part * part.tile_h + (ly % part.tile_h);
     // Camera::ray_for_pixel (camera.rs:45-64)
@@ -60,7 +70,7 @@ __global__ __launch_bounds__(256) void k_render(Scene sc, RtCamera cam, RenderPa
     V3 direction = normalize(pixel - origin);
     cn.primary = 1;
     Hit ph;
-    V3 col = color_at(sc, rp, Ray{origin, direction}, sc.recursion_limit, py * cam.hsize + px, cn, &ph);
+    V3 col = color_at<COUNT>(sc, rp, Ray{origin, direction}, sc.recursion_limit, py * cam.hsize + px, cn, &ph);
     size_t idx = (size_t)ly * cam.hsize + px;
     out[3 * idx + 0] = col.x;
     out[3 * idx + 1] = col.y;
@@ -73,19 +83,20 @@ __global__ __launch_bounds__(256) void k_render(Scene sc, RtCamera cam, RenderPa
 }
 
 // World::color_at for caller-supplied rays (world.rs:91-99).
+template <bool COUNT>
 __global__ __launch_bounds__(256) void k_color_at(Scene sc, RenderParams rp, const float* __restrict__ origins,
                                                   const float* __restrict__ directions, uint32_t n,
                                                   uint32_t remaining, float* __restrict__ out,
                                                   float* __restrict__ hit_t, int32_t* __restrict__ hit_id,
                                                   float* __restrict__ hit_uv, unsigned long long* counters) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  Counters cn = {0, 0, 0, 0, 0};
+  Counters cn = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (i < n) {
     Ray r{v3(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]),
           v3(directions[3 * i], directions[3 * i + 1], directions[3 * i + 2])};
     cn.primary = 1;
     Hit ph;
-    V3 col = color_at(sc, rp, r, remaining, i, cn, &ph);
+    V3 col = color_at<COUNT>(sc, rp, r, remaining, i, cn, &ph);
     if (out) {
       out[3 * i] = col.x;
       out[3 * i + 1] = col.y;
@@ -245,7 +256,7 @@ RenderParams make_params(const RtRenderOptions* o) {
 }
 
 int read_stats(RtContext* ctx, hipStream_t stream, RtStats* stats, double total_ms) {
-  unsigned long long h[8];
+  unsigned long long h[RT_N_COUNTERS];
   HIP_TRY(ctx, hipMemcpyAsync(h, ctx->d_counters, sizeof(h), hipMemcpyDeviceToHost, stream));
   HIP_TRY(ctx, hipStreamSynchronize(stream));
   float ms = 0.f;
@@ -255,6 +266,11 @@ int read_stats(RtContext* ctx, hipStream_t stream, RtStats* stats, double total_
   stats->reflect = h[2];
   stats->refract = h[3];
   stats->overflow = h[4];
+  stats->node_visits = h[5];
+  stats->tri_tests = h[6];
+  stats->shape_tests = h[7];
+  stats->shaded_hits = h[8];
+  stats->node_xforms = h[9];
   stats->kernel_ms = ms;
   stats->total_ms = total_ms;
   return RT_OK;
@@ -281,7 +297,7 @@ int rt_context_create(int device, RtContext** out) {
   if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
   if ((e = hipEventCreate(&c->ev0)) != hipSuccess) return bail(e, "hipEventCreate");
   if ((e = hipEventCreate(&c->ev1)) != hipSuccess) return bail(e, "hipEventCreate");
-  if ((e = hipMalloc((void**)&c->d_counters, 8 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc");
+  if ((e = hipMalloc((void**)&c->d_counters, RT_N_COUNTERS * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc");
   *out = c;
   return RT_OK;
 }
@@ -368,11 +384,12 @@ int rt_render_device(RtContext* ctx, const RtDeviceScene* ds, const RtCamera* ca
   Scene sc = ds->sc;
   sc.flags = opts ? opts->flags : 0;
   RenderParams rp = make_params(opts);
-  HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 8 * sizeof(unsigned long long), stream));
+  HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, RT_N_COUNTERS * sizeof(unsigned long long), stream));
   if (part.rows > 0) {
     dim3 grid((cam->hsize + 15) / 16, (part.rows + 15) / 16);
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
-    hipLaunchKernelGGL(k_render, grid, dim3(256), 0, stream, sc, *cam, rp, part, d_out_rgb,
+    auto kern = (sc.flags & RT_RENDER_COUNT_WORK) ? k_render<true> : k_render<false>;
+    hipLaunchKernelGGL(kern, grid, dim3(256), 0, stream, sc, *cam, rp, part, d_out_rgb,
                        d_aux ? d_aux->hit_mask : nullptr, d_aux ? d_aux->object_id : nullptr,
                        d_aux ? d_aux->hit_t : nullptr, ctx->d_counters);
     HIP_TRY(ctx, hipGetLastError());
@@ -478,12 +495,12 @@ int rt_color_at(RtContext* ctx, const RtDeviceScene* ds, const RtRenderOptions* 
   TRY_CLEAN(hipMalloc((void**)&d_id, (size_t)n * sizeof(int32_t)));
   TRY_CLEAN(hipMemcpyAsync(d_o, origins, n3, hipMemcpyHostToDevice, ctx->stream));
   TRY_CLEAN(hipMemcpyAsync(d_d, directions, n3, hipMemcpyHostToDevice, ctx->stream));
-  TRY_CLEAN(hipMemsetAsync(ctx->d_counters, 0, 8 * sizeof(unsigned long long), ctx->stream));
+  TRY_CLEAN(hipMemsetAsync(ctx->d_counters, 0, RT_N_COUNTERS * sizeof(unsigned long long), ctx->stream));
   Scene sc = ds->sc;
   sc.flags = opts ? opts->flags : 0;
   RenderParams rp = make_params(opts);
   TRY_CLEAN(hipEventRecord(ctx->ev0, ctx->stream));
-  hipLaunchKernelGGL(k_color_at, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, sc, rp, d_o, d_d, n, remaining,
+  hipLaunchKernelGGL(k_color_at<false>, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, sc, rp, d_o, d_d, n, remaining,
                      d_rgb, d_t, d_id, d_uv, ctx->d_counters);
   TRY_CLEAN(hipGetLastError());
   TRY_CLEAN(hipEventRecord(ctx->ev1, ctx->stream));

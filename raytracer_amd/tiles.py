@@ -1,0 +1,46 @@
+"""Interleaved scanline tiles: how one frame is split over N GPUs and put back together.
+
+Part ``p`` of ``n`` renders the rows ``r`` with ``(r // tile_h) % n == p``, compacted
+in increasing order — the same rule as RtRenderOptions.tile_h/n_parts/part (include/rt_abi.h).
+Pixels are independent (src/camera.rs:73-77), so the assembled canvas is byte-identical for any n.
+The exchange step is one all-gather of equal-sized row blocks (RCCL over xGMI on GPUs, gloo in
+the CPU tests) followed by one row permutation.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def part_rows(vsize: int, tile_h: int, n_parts: int, part: int) -> np.ndarray:
+    r = np.arange(vsize)
+    return r[(r // tile_h) % n_parts == part]
+
+
+def max_part_rows(vsize: int, tile_h: int, n_parts: int) -> int:
+    return max(len(part_rows(vsize, tile_h, n_parts, p)) for p in range(n_parts))
+
+
+def row_permutation(vsize: int, tile_h: int, n_parts: int) -> np.ndarray:
+    """perm[g] = position of global row g inside the padded all-gather buffer
+    (part-major, each part padded to max_part_rows)."""
+    m = max_part_rows(vsize, tile_h, n_parts)
+    perm = np.empty(vsize, dtype=np.int64)
+    for p in range(n_parts):
+        rows = part_rows(vsize, tile_h, n_parts, p)
+        perm[rows] = p * m + np.arange(len(rows))
+    return perm
+
+
+def gather_canvas(local: torch.Tensor, vsize: int, tile_h: int, group=None, perm: torch.Tensor = None,
+                  gathered: torch.Tensor = None) -> torch.Tensor:
+    """All-gather every rank's compacted rows ``local`` (max_part_rows, hsize, 3; trailing rows of
+    short parts are padding) and return the full (vsize, hsize, 3) canvas on every rank."""
+    n = dist.get_world_size(group)
+    if gathered is None:
+        gathered = torch.empty((n,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(gathered, local.contiguous(), group=group)
+    if perm is None:
+        perm = torch.from_numpy(row_permutation(vsize, tile_h, n)).to(local.device)
+    return gathered.view(n * local.shape[0], *local.shape[1:]).index_select(0, perm)
