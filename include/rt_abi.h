@@ -211,6 +211,8 @@ typedef struct {
 } RtRenderOptions;
 #define RT_RENDER_NO_PRUNE 0x1u   /* visit every node the reference visits (no distance pruning) */
 #define RT_RENDER_COUNT_WORK 0x2u /* instrumented kernel: also fill the work counters of RtStats (slower) */
+#define RT_RENDER_NO_ACCEL 0x4u   /* test every own triangle of a group linearly, as the reference does
+                                     (groups.rs:118-120), instead of through the library's auxiliary BVHs */
 
 /* Optional per-pixel side outputs of the PRIMARY ray, same compaction as the image. */
 typedef struct {
@@ -242,6 +244,19 @@ const char* rt_last_error(const RtContext*);
 /* Upload a flattened world; validates limits (RT_E_SCENE). */
 int rt_scene_create(RtContext*, const RtScene*, RtDeviceScene** out);
 void rt_scene_destroy(RtContext*, RtDeviceScene*);
+
+/* Diagnostics (host only, no GPU needed): the auxiliary BVHs rt_scene_create would build for this
+ * scene (raytracer_amd/csrc/rt_accel.h documents the node/triangle layout). No counterpart in the
+ * reference: the acceleration data is private to this library; tests use this view to check it. */
+typedef struct {
+  uint64_t n_nodes, n_tris, n_roots;
+  const void* nodes;       /* n_nodes x 64 B */
+  const void* tris;        /* n_tris x 48 B */
+  const uint32_t* root_of; /* per RtScene node: header index or 0xFFFFFFFF */
+  void* owner;
+} RtAccelView;
+int rt_accel_build(const RtScene*, RtAccelView* out);
+void rt_accel_free(RtAccelView*);
 
 /* Number of rows a (camera, options) pair renders on this part (for buffer sizing). */
 uint32_t rt_part_rows(const RtCamera*, const RtRenderOptions*);

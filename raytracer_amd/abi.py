@@ -12,7 +12,7 @@ RT_VCLASS_NEVER = 0xFFFFFFFF
 RT_NODE_ALL_TRIS, RT_NODE_PRUNABLE = 1, 2
 RT_CSG_LEFT_IS_SHAPE, RT_CSG_RIGHT_IS_SHAPE = 1, 2
 RT_JITTER_CONST, RT_JITTER_COUNTER = 0, 1
-RT_RENDER_NO_PRUNE, RT_RENDER_COUNT_WORK = 1, 2
+RT_RENDER_NO_PRUNE, RT_RENDER_COUNT_WORK, RT_RENDER_NO_ACCEL = 1, 2, 4
 
 # numpy dtypes of the device records (must match the C structs byte for byte)
 XFORM = np.dtype([("m", "<f4", 12)])
@@ -83,7 +83,17 @@ class RtStats(C.Structure):
                 ("kernel_ms", C.c_double), ("total_ms", C.c_double)]
 
 
-EXPORTS = ["rt_abi_version", "rt_context_create", "rt_context_destroy", "rt_last_error", "rt_scene_create",
+class RtAccelView(C.Structure):
+    _fields_ = [("n_nodes", C.c_uint64), ("n_tris", C.c_uint64), ("n_roots", C.c_uint64), ("nodes", C.c_void_p),
+                ("tris", C.c_void_p), ("root_of", C.c_void_p), ("owner", C.c_void_p)]
+
+
+AUX_NODE = np.dtype([("lmin", "<f4", 3), ("left", "<u4"), ("lmax", "<f4", 3), ("lcount", "<u4"),
+                     ("rmin", "<f4", 3), ("right", "<u4"), ("rmax", "<f4", 3), ("rcount", "<u4")])
+AUX_TRI = np.dtype([("p1", "<f4", 3), ("k", "<u4"), ("e1", "<f4", 3), ("pad1", "<f4"), ("e2", "<f4", 3), ("pad2", "<f4")])
+assert AUX_NODE.itemsize == 64 and AUX_TRI.itemsize == 48
+
+EXPORTS = ["rt_accel_build", "rt_accel_free", "rt_abi_version", "rt_context_create", "rt_context_destroy", "rt_last_error", "rt_scene_create",
            "rt_scene_destroy", "rt_part_rows", "rt_render", "rt_render_device", "rt_color_at"]
 
 
@@ -95,6 +105,8 @@ def declare(lib: C.CDLL) -> None:
     lib.rt_last_error.restype, lib.rt_last_error.argtypes = C.c_char_p, [P]
     lib.rt_scene_create.restype, lib.rt_scene_create.argtypes = C.c_int, [P, C.POINTER(RtScene), C.POINTER(P)]
     lib.rt_scene_destroy.restype, lib.rt_scene_destroy.argtypes = None, [P, P]
+    lib.rt_accel_build.restype, lib.rt_accel_build.argtypes = C.c_int, [C.POINTER(RtScene), C.POINTER(RtAccelView)]
+    lib.rt_accel_free.restype, lib.rt_accel_free.argtypes = None, [C.POINTER(RtAccelView)]
     lib.rt_part_rows.restype, lib.rt_part_rows.argtypes = C.c_uint32, [C.POINTER(RtCamera), C.POINTER(RtRenderOptions)]
     lib.rt_render.restype = C.c_int
     lib.rt_render.argtypes = [P, P, C.POINTER(RtCamera), C.POINTER(RtRenderOptions), P, C.POINTER(RtAux),
@@ -112,6 +124,19 @@ def _view(ptr, count, dtype):
         return np.zeros(0, dtype=dtype)
     buf = (C.c_char * (count * dtype.itemsize)).from_address(ptr)
     return np.frombuffer(buf, dtype=dtype, count=count).copy()
+
+
+def accel_arrays(lib: C.CDLL, s: RtScene) -> dict:
+    """The auxiliary BVHs of a flattened scene as numpy arrays (copies)."""
+    v = RtAccelView()
+    rc = lib.rt_accel_build(C.byref(s), C.byref(v))
+    if rc != RT_OK:
+        raise RuntimeError(f"rt_accel_build failed ({rc})")
+    try:
+        return {"nodes": _view(v.nodes, v.n_nodes, AUX_NODE), "tris": _view(v.tris, v.n_tris, AUX_TRI),
+                "root_of": _view(v.root_of, v.n_roots, np.dtype("<u4"))}
+    finally:
+        lib.rt_accel_free(C.byref(v))
 
 
 def scene_arrays(s: RtScene) -> dict:

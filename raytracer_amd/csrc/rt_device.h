@@ -16,6 +16,9 @@
 #define RT_CSG_CAP 32        // per-ray intersection entries while evaluating one csg tree
 #define RT_CSG_DEPTH 8       // csg tree depth
 #define RT_XS_CAP 96         // per-ray entries for the n1/n2 container walk
+#define RT_AUX_STACK 24      // per-lane auxiliary-BVH stack entries, kept in LDS (rt_accel.h kMaxDepth + 2)
+#define RT_BLOCK 256         // every kernel that traces runs 256-thread blocks (LDS stack stride)
+#define RT_AUX_NONE 0xFFFFFFFFu
 
 namespace rtd {
 
@@ -68,6 +71,8 @@ struct Scene {
   const RtImage* images;
   const float* texels;
   const RtLight* lights;
+  const float4* aux_nodes;  // library-built auxiliary BVHs (rt_accel.h): 4 float4 per node
+  const float4* aux_tris;   // their leaf triangles: 3 float4 per triangle, p1.w = offset in the group
   uint32_t n_shapes, n_nodes, n_csg_roots, n_lights, n_loose, recursion_limit;
   uint32_t flags;  // RT_RENDER_*
 };
@@ -472,6 +477,105 @@ __device__ inline void csg_eval(const Scene& sc, RtCsgRoot root, const Ray& ray,
 }
 
 // ---------------------------------------------------------------------------------------
+// Auxiliary BVH under a group whose own shapes are many identity-transform triangles
+// (rt_accel.h).  Same Möller–Trumbore arithmetic on the same triangles as the reference's
+// linear loop (groups.rs:118-120); the BVH only skips triangles the test would have rejected.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t* aux_stack() {
+  __shared__ uint32_t stk[RT_AUX_STACK * RT_BLOCK];
+  return stk + threadIdx.x;
+}
+template <bool COUNT, class Sink>
+__device__ __forceinline__ void tris_linear(const Scene& sc, uint32_t first_shape, uint32_t first_tri, uint32_t n,
+                                            const Ray& cur, Sink& sink, Counters& cn) {
+  if (COUNT) cn.tri_tests += n;
+  for (uint32_t k = 0; k < n; k++) {
+    V3 p1, e1, e2;
+    load_tri(sc, first_tri + k, p1, e1, e2);
+    float t, u, v;
+    if (isect_triangle(cur, p1, e1, e2, t, u, v)) sink.add(t, first_shape + k, u, v);
+  }
+}
+// Conservative slab test against a box widened by `pad`: never reports a miss for a line that comes
+// within the padding of the box contents; NaNs (0 * inf) count as "inside".
+__device__ __forceinline__ bool aux_box(V3 o, V3 inv, float pad, float4 mn, float4 mx, float lo, float hi,
+                                        float& tnear) {
+  float ax = ((mn.x - pad) - o.x) * inv.x, bx = ((mx.x + pad) - o.x) * inv.x;
+  float ay = ((mn.y - pad) - o.y) * inv.y, by = ((mx.y + pad) - o.y) * inv.y;
+  float az = ((mn.z - pad) - o.z) * inv.z, bz = ((mx.z + pad) - o.z) * inv.z;
+  float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz));
+  float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz));
+  tn = tn - 2e-6f * __builtin_fabsf(tn);
+  tf = tf + 2e-6f * __builtin_fabsf(tf);
+  tnear = tn;
+  return !(tn > tf) && !(tn > hi) && !(tf < lo);
+}
+template <bool COUNT, class Sink>
+__device__ inline void aux_intersect(const Scene& sc, uint32_t root, uint32_t first_shape, uint32_t first_tri,
+                                     uint32_t n_shapes, const Ray& cur, Sink& sink, Counters& cn) {
+  const float4* A = sc.aux_nodes + 4u * (size_t)root;
+  float4 h0 = A[0], h1 = A[1];
+  // Ray-dependent widening (DESIGN.md "Auxiliary BVH"): in f32 the reference's triangle test accepts a
+  // line that passes the triangle's plane up to 16u * K * (|s| + L) outside it (u = 2^-24,
+  // K = |e1||e2||d| / |det| <= 1e4 * |e1||e2||d| because |det| >= 1e-4 for every accepted hit, |s| = distance
+  // origin -> p1).  With S = farthest distance from the origin to the tree's triangles, a box widened by
+  // 1.5 * that bound can only be missed by lines the triangle test rejects.
+  V3 oc = cur.o - v3(h0.x, h0.y, h0.z);
+  float S = magnitude(oc) + h0.w;
+  float dm = magnitude(cur.d);
+  float pad = (0.0143f * h1.y) * (dm * (S + h1.x));
+  if (!(pad < h0.w)) {  // NaN/inf, or wider than the whole tree: the linear loop is the better (and exact) choice
+    tris_linear<COUNT>(sc, first_shape, first_tri, n_shapes, cur, sink, cn);
+    return;
+  }
+  V3 inv = v3(__builtin_amdgcn_rcpf(cur.d.x), __builtin_amdgcn_rcpf(cur.d.y), __builtin_amdgcn_rcpf(cur.d.z));
+  uint32_t* stk = aux_stack();
+  int sp = 0;
+  uint32_t ref = (root + 1u) << 3;
+  // the computed t of an accepted hit lies within 13u * K * |s| / |d| < 0.55 * pad / |d| of the line's true
+  // crossing of the triangle's plane, which is inside the widened box: slack for the t-range pruning
+  const float tpad = pad / dm;
+  const float lo = (Sink::wants_negative ? -__builtin_inff() : 0.f) - tpad;
+  while (true) {
+    uint32_t cnt = ref & 7u, idx = ref >> 3;
+    if (cnt == 0u) {
+      const float4* N = sc.aux_nodes + 4u * (size_t)idx;
+      float4 n0 = N[0], n1 = N[1], n2 = N[2], n3 = N[3];
+      if (COUNT) cn.node_visits += 2;
+      float lim = sink.limit();
+      float hi = (lim + 1e-5f * __builtin_fabsf(lim)) + tpad;
+      float tl, tr;
+      bool hl = aux_box(cur.o, inv, pad, n0, n1, lo, hi, tl);
+      bool hr = aux_box(cur.o, inv, pad, n2, n3, lo, hi, tr);
+      uint32_t rl = (__float_as_uint(n0.w) << 3) | __float_as_uint(n1.w);
+      uint32_t rr = (__float_as_uint(n2.w) << 3) | __float_as_uint(n3.w);
+      if (hl && hr) {
+        bool left_first = !(tr < tl);
+        ref = left_first ? rl : rr;
+        if (sp < RT_AUX_STACK) stk[(sp++) * RT_BLOCK] = left_first ? rr : rl;
+        else cn.overflow++;
+        continue;
+      }
+      if (hl || hr) {
+        ref = hl ? rl : rr;
+        continue;
+      }
+    } else {
+      if (COUNT) cn.tri_tests += cnt;
+      const float4* T = sc.aux_tris + 3u * (size_t)idx;
+      for (uint32_t k = 0; k < cnt; k++) {
+        float4 a = T[3 * k], b = T[3 * k + 1], c = T[3 * k + 2];
+        float t, u, v;
+        if (isect_triangle(cur, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), v3(c.x, c.y, c.z), t, u, v))
+          sink.add(t, first_shape + __float_as_uint(a.w), u, v);
+      }
+    }
+    if (sp == 0) break;
+    ref = stk[(--sp) * RT_BLOCK];
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // World::intersect (world.rs:44-62) as one traversal feeding a sink.
 // Groups: stackless depth-first walk over the DFS-ordered node array (skip pointers); the ray is
 // re-expressed in a group's space when the group has a non-identity transform (groups.rs:127-133)
@@ -534,14 +638,11 @@ __device__ inline void world_intersect(const Scene& sc, const Ray& ray, Sink& si
       }
       uint32_t first_shape = w2.x, n_shapes = w2.y;
       if (flags & RT_NODE_ALL_TRIS) {
-        uint32_t first_tri = w3.x;
-        if (COUNT) cn.tri_tests += n_shapes;
-        for (uint32_t k = 0; k < n_shapes; k++) {
-          V3 p1, e1, e2;
-          load_tri(sc, first_tri + k, p1, e1, e2);
-          float t, u, v;
-          if (isect_triangle(cur, p1, e1, e2, t, u, v)) sink.add(t, first_shape + k, u, v);
-        }
+        uint32_t first_tri = w3.x, aux = w3.w;  // device copy: n_children is replaced by the aux root
+        if (aux != RT_AUX_NONE && !(sc.flags & RT_RENDER_NO_ACCEL))
+          aux_intersect<COUNT>(sc, aux, first_shape, first_tri, n_shapes, cur, sink, cn);
+        else
+          tris_linear<COUNT>(sc, first_shape, first_tri, n_shapes, cur, sink, cn);
       } else {
         if (COUNT) cn.shape_tests += n_shapes;
         for (uint32_t k = 0; k < n_shapes; k++) shape_intersect(sc, first_shape + k, cur, sink);

@@ -11,6 +11,7 @@
 #include <string>
 #include <vector>
 
+#include "rt_accel.h"
 #include "rt_device.h"
 
 using namespace rtd;
@@ -128,6 +129,7 @@ struct RtDeviceScene {
   Scene sc{};
   std::vector<void*> allocs;
   RtContext* owner = nullptr;
+  size_t aux_nodes = 0, aux_tris = 0;
 };
 
 namespace {
@@ -334,7 +336,28 @@ int rt_scene_create(RtContext* ctx, const RtScene* s, RtDeviceScene** out) {
   UP(d.shapes, s->shapes, (size_t)s->n_shapes)
   UP(tg, s->tri_geom, (size_t)s->n_tris)
   UP(tn, s->tri_normals, (size_t)s->n_tris)
-  UP(d.nodes, s->nodes, (size_t)s->n_nodes)
+  {
+    // the library's own acceleration data: auxiliary BVHs under triangle-heavy groups (rt_accel.h);
+    // the device copy of a node carries its aux root in the slot of n_children (unused on the device)
+    rtaccel::Result acc = rtaccel::build(s);
+    std::vector<RtNode> nodes(s->nodes, s->nodes + s->n_nodes);
+    for (uint32_t i = 0; i < s->n_nodes; i++) nodes[i].n_children = acc.root_of[i];
+    const rtaccel::Node* an = nullptr;
+    const rtaccel::Tri* at = nullptr;
+    UP(d.nodes, nodes.data(), nodes.size())
+    UP(an, acc.nodes.data(), acc.nodes.size())
+    UP(at, acc.tris.data(), acc.tris.size())
+    d.aux_nodes = reinterpret_cast<const float4*>(an);
+    d.aux_tris = reinterpret_cast<const float4*>(at);
+    ds->aux_nodes = acc.nodes.size();
+    ds->aux_tris = acc.tris.size();
+    // uploads above are asynchronous copies from these temporaries
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+      rt_scene_destroy(ctx, ds);
+      return fail(ctx, RT_E_DEVICE, std::string("scene upload: ") + hipGetErrorString(e));
+    }
+  }
   UP(d.csg_nodes, s->csg_nodes, (size_t)s->n_csg_nodes)
   UP(d.csg_roots, s->csg_roots, (size_t)s->n_csg_roots)
   UP(d.materials, s->materials, (size_t)s->n_materials)
@@ -367,6 +390,23 @@ void rt_scene_destroy(RtContext* ctx, RtDeviceScene* ds) {
   if (ctx) (void)hipSetDevice(ctx->device);
   for (void* p : ds->allocs) (void)hipFree(p);
   delete ds;
+}
+
+int rt_accel_build(const RtScene* s, RtAccelView* out) {
+  if (!s || !out) return RT_E_ABI;
+  rtaccel::Result* r = new rtaccel::Result(rtaccel::build(s));
+  out->n_nodes = r->nodes.size();
+  out->n_tris = r->tris.size();
+  out->n_roots = r->root_of.size();
+  out->nodes = r->nodes.data();
+  out->tris = r->tris.data();
+  out->root_of = r->root_of.data();
+  out->owner = r;
+  return RT_OK;
+}
+void rt_accel_free(RtAccelView* v) {
+  if (v && v->owner) delete static_cast<rtaccel::Result*>(v->owner);
+  if (v) *v = RtAccelView{};
 }
 
 uint32_t rt_part_rows(const RtCamera* cam, const RtRenderOptions* o) { return cam ? make_part(cam, o).rows : 0; }
