@@ -39,8 +39,9 @@ def gather_canvas(local: torch.Tensor, vsize: int, tile_h: int, group=None, perm
     short parts are padding) and return the full (vsize, hsize, 3) canvas on every rank."""
     n = dist.get_world_size(group)
     if gathered is None:
-        gathered = torch.empty((n,) + tuple(local.shape), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(gathered, local.contiguous(), group=group)
+        gathered = torch.empty((n * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    flat = gathered.view(n * local.shape[0], *local.shape[1:])  # concatenated form: accepted by RCCL and gloo
+    dist.all_gather_into_tensor(flat, local.contiguous(), group=group)
     if perm is None:
         perm = torch.from_numpy(row_permutation(vsize, tile_h, n)).to(local.device)
-    return gathered.view(n * local.shape[0], *local.shape[1:]).index_select(0, perm)
+    return flat.index_select(0, perm)

@@ -28,3 +28,11 @@ def scene_path(name):
 
 def golden_path(name):
     return os.path.join(ROOT, "tests", "golden", f"{name}.png")
+
+
+def small_dragons(nu=64, nv=48):
+    """dragons.yaml (6 instances, nested transformed groups, `divide: 10`, transparent shadow-less
+    bbox cubes) over a small synthetic stand-in for dragon.obj: 2*nu*nv triangles per instance."""
+    from raytracer_amd import synth
+    from raytracer_amd.scene import Scene
+    return Scene.from_file(scene_path("dragons"), meshes={"dragon.obj": synth.synth_dragon(nu, nv)})

@@ -1,0 +1,229 @@
+"""Parity of the HIP render path against the CPU oracle, through the C ABI (librt_hip.so via
+librt_host.so / ctypes).  Bars (BASELINE.json north_star): primary hit mask and object-id map
+bit-exact; 8-bit channels within +-1 LSB on >= 99.9 % of pixels (tolerance written in `check`).
+At BASELINE's full sizes (4K) the oracle is too slow, so those cases use size-independent
+properties: parts reassemble to the same bytes, pruning / auxiliary BVHs change nothing."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+from PIL import Image
+
+from conftest import golden_path, scene_path, small_dragons
+from raytracer_amd import abi, builder as B, host
+from raytracer_amd.canvas import to_u8
+from raytracer_amd.scene import Scene
+
+pytestmark = pytest.mark.gpu
+
+LSB_FRACTION = 0.999  # >= 99.9 % of pixels within +-1 LSB per channel
+
+
+def _oracle():
+    from oracle import oracle
+    return oracle
+
+
+def check(g, r, name):
+    assert g.stats["overflow"] == 0, name
+    assert np.array_equal(g.hit_mask, r.hit_mask), f"{name}: primary hit mask differs"
+    assert np.array_equal(g.object_id, r.object_id), f"{name}: primary object ids differ"
+    hit = r.hit_mask.astype(bool)
+    assert np.array_equal(g.hit_t[hit].view(np.uint32), r.hit_t[hit].view(np.uint32)), f"{name}: primary hit t differs"
+    d = np.abs(to_u8(g.rgb).astype(int) - to_u8(r.rgb).astype(int)).max(axis=2)
+    frac = float((d <= 1).mean())
+    assert frac >= LSB_FRACTION, f"{name}: only {frac:.5f} of pixels within 1 LSB"
+    for k in ("primary", "shadow", "reflect", "refract"):
+        assert g.stats[k] == r.stats[k], f"{name}: {k} ray count {g.stats[k]} != oracle {r.stats[k]}"
+
+
+SCENES = [("basic_scene", None), ("cover", (640, 640)), ("csg", None), ("checkered_cube", None),
+          ("checkered_sphere", None), ("checkered_plane", None), ("checkered_cylinder", None), ("space_ship", (640, 360)),
+          ("space_teapot", (640, 360))]
+
+
+@pytest.mark.parametrize("name,size", SCENES)
+def test_scene_matches_oracle(name, size, obj_files):
+    scene = Scene.from_file(scene_path(name), obj_files=obj_files)
+    cam = scene.camera(*size) if size else scene.camera()
+    g = scene.build(host.new_world(0)).render(cam, aux=True)
+    r = scene.build(_oracle().new_world()).render(cam, aux=True)
+    check(g, r, name)
+
+
+@pytest.mark.parametrize("name", ["basic_scene", "cover", "csg", "checkered_cube", "checkered_sphere",
+                                  "checkered_plane", "checkered_cylinder", "space_ship", "space_teapot"])
+def test_scene_matches_reference_render(name, obj_files):
+    """Directly against the reference's own renders (tests/golden = samples/rendered), native size."""
+    scene = Scene.from_file(scene_path(name), obj_files=obj_files)
+    g = scene.build(host.new_world(0)).render(scene.camera())
+    gold = np.asarray(Image.open(golden_path(name)).convert("RGB"), dtype=np.uint8)
+    d = np.abs(to_u8(g.rgb).astype(int) - gold.astype(int)).max(axis=2)
+    assert float((d <= 1).mean()) >= LSB_FRACTION, f"{name}: {(d > 1).sum()} pixels off by more than 1 LSB"
+
+
+@pytest.mark.parametrize("mode,seed", [(B.JITTER_CONST, 0), (B.JITTER_COUNTER, 1), (B.JITTER_COUNTER, 12345)])
+def test_soft_shadows_area_light(mode, seed):
+    scene = Scene.from_file(scene_path("soft_shadows"))
+    cam = scene.camera(320, 180)
+    ro = B.RenderOptions(jitter_mode=mode, seed=seed)
+    g = scene.build(host.new_world(0)).render(cam, ro, aux=True)
+    r = scene.build(_oracle().new_world()).render(cam, ro, aux=True)
+    check(g, r, f"soft_shadows mode={mode}")
+    assert g.stats["shadow"] > 100 * 0.5 * cam.hsize * cam.vsize  # 10x10 samples per shaded hit
+
+
+def test_small_dragons_matches_oracle():
+    scene = small_dragons()
+    cam = scene.camera(600, 240)
+    g = scene.build(host.new_world(0)).render(cam, aux=True)
+    r = scene.build(_oracle().new_world()).render(cam, aux=True)
+    check(g, r, "small dragons")
+    assert g.stats["refract"] > 0 and g.stats["reflect"] > 0  # the transparent shadow-less bbox cubes are in play
+
+
+def test_color_at_random_rays(obj_files):
+    """rt_color_at vs World::color_at / Intersections::hit of the oracle on arbitrary rays, including
+    axis-parallel directions (|d| < 1e-4 slab rule, Q7) and non-unit directions."""
+    scene = small_dragons(32, 24)
+    rng = np.random.RandomState(7)
+    n = 20000
+    o = rng.uniform(-12, 12, size=(n, 3)).astype(np.float32)
+    o[:, 1] = np.abs(o[:, 1]) + 0.2
+    tgt = rng.uniform(-4, 4, size=(n, 3)).astype(np.float32)
+    d = tgt - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d[:2000] *= rng.uniform(0.05, 20.0, size=(2000, 1)).astype(np.float32)
+    d[2000:2300, 0] = 0.0
+    d[2300:2600, 1] = 5e-5
+    d[2600:2900, 2] = 0.0
+    gw, ow = scene.build(host.new_world(0)), scene.build(_oracle().new_world())
+    for remaining in (0, 4):
+        grgb, gt, gid, guv = gw.color_at(o, d, remaining)
+        rrgb, rt, rid, ruv = ow.color_at(o, d, remaining)
+        assert np.array_equal(gid, rid)
+        hit = rid >= 0
+        assert hit.mean() > 0.2
+        assert np.array_equal(gt[hit].view(np.uint32), rt[hit].view(np.uint32))
+        assert np.array_equal(guv[hit].view(np.uint32), ruv[hit].view(np.uint32))
+        dd = np.abs(to_u8(grgb).astype(int) - to_u8(rrgb).astype(int)).max(axis=1)
+        assert (dd <= 1).mean() >= LSB_FRACTION
+
+
+def test_kat_world_default_on_gpu():
+    """world.rs:197-205 on the device: the default world, one ray that misses and one that hits."""
+    w = host.new_world(0)
+    w.add_point_light((-10, 10, -10), (1, 1, 1))
+    w.add_shape(w.shape("sphere", (), B.Material(color=(0.8, 1.0, 0.6), diffuse=0.7, specular=0.2)))
+    w.add_shape(w.shape("sphere", [("scale", 0.5, 0.5, 0.5)]))
+    rgb, t, ids, _ = w.color_at([(0, 0, -5), (0, 0, -5)], [(0, 1, 0), (0, 0, 1)], 1)
+    assert np.array_equal(rgb[0], [0, 0, 0]) and ids[0] == -1 and np.isnan(t[0])
+    assert np.all(np.abs(rgb[1] - np.array([0.38066, 0.47583, 0.2855])) < 1e-4) and ids[1] == 0 and t[1] == 4.0
+
+
+# ---- the raw C ABI ------------------------------------------------------------------------------------
+class Raw:
+    def __init__(self, scene, size):
+        import torch
+        self.torch = torch
+        self.lib = host.hip_lib()
+        self.hw = scene.build(host.new_world(0))
+        self.ctx, self.ds = self.hw.device_scene()
+        self.cam = scene.camera(*size)
+        self.rcam = self.hw.rt_camera(self.cam)
+        self.dev = torch.device("cuda", 0)
+
+    def render(self, flags=0, tile_h=1, n_parts=1, part=0, mode=abi.RT_JITTER_COUNTER, want_stats=True):
+        torch = self.torch
+        opts = abi.RtRenderOptions(mode, 0.5, 1, tile_h, n_parts, part, flags)
+        rows = int(self.lib.rt_part_rows(C.byref(self.rcam), C.byref(opts)))
+        out = torch.zeros((max(rows, 1), self.cam.hsize, 3), dtype=torch.float32, device=self.dev)
+        oid = torch.full((max(rows, 1), self.cam.hsize), -7, dtype=torch.int32, device=self.dev)
+        aux = abi.RtAux(None, oid.data_ptr(), None)
+        st = abi.RtStats()
+        rc = self.lib.rt_render_device(self.ctx, self.ds, C.byref(self.rcam), C.byref(opts), out.data_ptr(), C.byref(aux),
+                                       None, C.byref(st) if want_stats else None)
+        assert rc == abi.RT_OK, self.lib.rt_last_error(self.ctx).decode()
+        torch.cuda.synchronize()
+        return out[:rows].cpu().numpy(), oid[:rows].cpu().numpy(), st
+
+
+@pytest.mark.parametrize("name,size", [("cover", (3840, 2160)), ("dragons", (3840, 2160))])
+def test_parts_reassemble_at_4k(name, size):
+    """BASELINE configs at full size: the frame rendered as 1, 2, 4 and 8 interleaved parts is the same
+    bytes (what the 1/2/4/8-GPU runs gather), and rendering twice gives the same bytes."""
+    from raytracer_amd import synth, tiles
+    meshes = {"dragon.obj": synth.synth_dragon(220, 220)} if name == "dragons" else None
+    scene = Scene.from_file(scene_path(name), meshes=meshes)
+    raw = Raw(scene, size)
+    full, ids, st = raw.render()
+    again, _, _ = raw.render()
+    assert np.array_equal(full.view(np.uint32), again.view(np.uint32))
+    assert st.overflow == 0 and st.primary == size[0] * size[1]
+    for n in (2, 4, 8):
+        canvas = np.empty_like(full)
+        idc = np.empty_like(ids)
+        rays = 0
+        for p in range(n):
+            rgb, oid, s = raw.render(tile_h=2, n_parts=n, part=p)
+            rows = tiles.part_rows(size[1], 2, n, p)
+            canvas[rows], idc[rows] = rgb, oid
+            rays += s.primary + s.shadow + s.reflect + s.refract
+        assert np.array_equal(canvas.view(np.uint32), full.view(np.uint32)), f"{name}: {n} parts differ from 1"
+        assert np.array_equal(idc, ids)
+        assert rays == st.primary + st.shadow + st.reflect + st.refract
+
+
+def test_accel_and_pruning_change_nothing_at_4k():
+    """dragons at 4K (BASELINE config 5, synthetic mesh): the auxiliary BVHs and the distance pruning are
+    pure culling — bit-identical image and ids with either or both switched off."""
+    from raytracer_amd import synth
+    scene = Scene.from_file(scene_path("dragons"), meshes={"dragon.obj": synth.synth_dragon(330, 330)})
+    raw = Raw(scene, (3840, 2160))
+    base, ids, st = raw.render(flags=abi.RT_RENDER_COUNT_WORK)
+    assert st.tri_tests > 0 and st.node_visits > 0
+    for flags in (abi.RT_RENDER_NO_ACCEL, abi.RT_RENDER_NO_PRUNE, abi.RT_RENDER_NO_ACCEL | abi.RT_RENDER_NO_PRUNE):
+        rgb, oid, s = raw.render(flags=flags)
+        assert np.array_equal(rgb.view(np.uint32), base.view(np.uint32)), f"flags={flags}"
+        assert np.array_equal(oid, ids)
+
+
+def test_abi_error_paths():
+    lib = host.hip_lib()
+    scene = Scene.from_file(scene_path("basic_scene"))
+    raw = Raw(scene, (16, 16))
+    # part >= n_parts
+    opts = abi.RtRenderOptions(0, 0.5, 0, 1, 2, 2, 0)
+    out = raw.torch.zeros((16, 16, 3), dtype=raw.torch.float32, device=raw.dev)
+    assert lib.rt_render_device(raw.ctx, raw.ds, C.byref(raw.rcam), C.byref(opts), out.data_ptr(), None, None, None) == abi.RT_E_ABI
+    # NULL arguments
+    assert lib.rt_render_device(raw.ctx, raw.ds, None, None, out.data_ptr(), None, None, None) == abi.RT_E_ABI
+    # empty camera
+    cam0 = abi.RtCamera(0, 16, 0.01, 1, 1)
+    assert lib.rt_render_device(raw.ctx, raw.ds, C.byref(cam0), None, out.data_ptr(), None, None, None) == abi.RT_E_ABI
+    # a scene with an out-of-range index is rejected before anything reaches the GPU
+    fs = raw.hw.flatten()
+    arr = abi.scene_arrays(fs)
+    shapes = arr["shapes"].copy()
+    shapes["material"][0] = 10 ** 6
+    bad = abi.RtScene.from_buffer_copy(fs)
+    bad.shapes = shapes.ctypes.data
+    ds = C.c_void_p()
+    assert lib.rt_scene_create(raw.ctx, C.byref(bad), C.byref(ds)) == abi.RT_E_SCENE
+    assert b"material" in lib.rt_last_error(raw.ctx)
+    bad2 = abi.RtScene.from_buffer_copy(fs)
+    bad2.abi_version = 99
+    assert lib.rt_scene_create(raw.ctx, C.byref(bad2), C.byref(ds)) == abi.RT_E_ABI
+    # a part with no rows renders nothing and succeeds (ragged: 3 rows over 8 parts)
+    scene3 = Raw(scene, (8, 3))
+    rgb, _, st = scene3.render(tile_h=1, n_parts=8, part=5)
+    assert rgb.shape[0] == 0 and st.primary == 0
+
+
+def test_world_without_lights_is_black():
+    """world.rs:66-86: no light, no colour (Q4) — and no secondary rays are spawned."""
+    w = host.new_world(0)
+    w.add_shape(w.shape("sphere", (), B.Material(reflective=0.5)))
+    rgb, t, ids, _ = w.color_at([(0, 0, -5)], [(0, 0, 1)], 4)
+    assert np.array_equal(rgb[0], [0, 0, 0]) and ids[0] == 0 and t[0] == 4.0
