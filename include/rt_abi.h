@@ -273,7 +273,8 @@ int rt_render_device(RtContext*, const RtDeviceScene*, const RtCamera*, const Rt
 
 /* World::color_at(ray, remaining) (src/world.rs:91-99) and Intersections::hit()
  * (src/intersections.rs:94-96) for n caller-supplied rays (host pointers): origins/directions
- * n*3, out_rgb n*3, hit_t n (NaN on miss), hit_id n (-1 on miss), hit_uv n*2; outputs may be NULL. */
+ * n*3, out_rgb n*3, hit_t n (NaN on miss), hit_id n (-1 on miss), hit_uv n*2 (the (u,v) of a smooth-triangle
+ * hit, src/intersections.rs:34-41; 0 for every other shape); outputs may be NULL. */
 int rt_color_at(RtContext*, const RtDeviceScene*, const RtRenderOptions*, const float* origins,
                 const float* directions, uint32_t n, uint32_t remaining, float* out_rgb, float* hit_t,
                 int32_t* hit_id, float* hit_uv, RtStats* stats);

@@ -106,7 +106,9 @@ def test_color_at_random_rays(obj_files):
         hit = rid >= 0
         assert hit.mean() > 0.2
         assert np.array_equal(gt[hit].view(np.uint32), rt[hit].view(np.uint32))
-        assert np.array_equal(guv[hit].view(np.uint32), ruv[hit].view(np.uint32))
+        smooth = hit & (ruv[:, 0] != np.finfo(np.float32).max)  # (u, v) exist only for smooth triangles
+        assert smooth.sum() > 100                                    # (intersections.rs:34-41: f32::MAX otherwise)
+        assert np.array_equal(guv[smooth].view(np.uint32), ruv[smooth].view(np.uint32))
         dd = np.abs(to_u8(grgb).astype(int) - to_u8(rrgb).astype(int)).max(axis=1)
         assert (dd <= 1).mean() >= LSB_FRACTION
 
