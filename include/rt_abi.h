@@ -228,6 +228,7 @@ typedef struct {
   /* work counters, only with RT_RENDER_COUNT_WORK (else 0): what the roofline's algorithmic
    * bytes/flops are computed from (DESIGN.md "Measurement") */
   uint64_t node_visits, tri_tests, shape_tests, shaded_hits, node_xforms;
+  uint64_t aux_tests;  /* box tests against the library's auxiliary BVHs */
   double kernel_ms;    /* device time of the render kernel(s), HIP events on the render stream */
   double total_ms;     /* wall time of the call */
 } RtStats;
@@ -252,7 +253,8 @@ typedef struct {
   uint64_t n_nodes, n_tris, n_roots;
   const void* nodes;       /* n_nodes x 64 B */
   const void* tris;        /* n_tris x 48 B */
-  const uint32_t* root_of; /* per RtScene node: header index or 0xFFFFFFFF */
+  const uint32_t* root_of; /* per RtScene node: header index of the BVH covering its subtree, or 0xFFFFFFFF */
+  const uint32_t* gate_next; /* per RtScene node inside a covered subtree: next group whose box test is not implied */
   void* owner;
 } RtAccelView;
 int rt_accel_build(const RtScene*, RtAccelView* out);

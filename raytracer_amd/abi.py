@@ -80,17 +80,18 @@ class RtStats(C.Structure):
     _fields_ = [("primary", C.c_uint64), ("shadow", C.c_uint64), ("reflect", C.c_uint64), ("refract", C.c_uint64),
                 ("overflow", C.c_uint64), ("node_visits", C.c_uint64), ("tri_tests", C.c_uint64),
                 ("shape_tests", C.c_uint64), ("shaded_hits", C.c_uint64), ("node_xforms", C.c_uint64),
-                ("kernel_ms", C.c_double), ("total_ms", C.c_double)]
+                ("aux_tests", C.c_uint64), ("kernel_ms", C.c_double), ("total_ms", C.c_double)]
 
 
 class RtAccelView(C.Structure):
     _fields_ = [("n_nodes", C.c_uint64), ("n_tris", C.c_uint64), ("n_roots", C.c_uint64), ("nodes", C.c_void_p),
-                ("tris", C.c_void_p), ("root_of", C.c_void_p), ("owner", C.c_void_p)]
+                ("tris", C.c_void_p), ("root_of", C.c_void_p), ("gate_next", C.c_void_p), ("owner", C.c_void_p)]
 
 
 AUX_NODE = np.dtype([("lmin", "<f4", 3), ("left", "<u4"), ("lmax", "<f4", 3), ("lcount", "<u4"),
                      ("rmin", "<f4", 3), ("right", "<u4"), ("rmax", "<f4", 3), ("rcount", "<u4")])
-AUX_TRI = np.dtype([("p1", "<f4", 3), ("k", "<u4"), ("e1", "<f4", 3), ("pad1", "<f4"), ("e2", "<f4", 3), ("pad2", "<f4")])
+AUX_TRI = np.dtype([("p1", "<f4", 3), ("shape", "<u4"), ("e1", "<f4", 3), ("owner", "<u4"), ("e2", "<f4", 3),
+                    ("pad", "<u4")])
 assert AUX_NODE.itemsize == 64 and AUX_TRI.itemsize == 48
 
 EXPORTS = ["rt_accel_build", "rt_accel_free", "rt_abi_version", "rt_context_create", "rt_context_destroy", "rt_last_error", "rt_scene_create",
@@ -134,7 +135,8 @@ def accel_arrays(lib: C.CDLL, s: RtScene) -> dict:
         raise RuntimeError(f"rt_accel_build failed ({rc})")
     try:
         return {"nodes": _view(v.nodes, v.n_nodes, AUX_NODE), "tris": _view(v.tris, v.n_tris, AUX_TRI),
-                "root_of": _view(v.root_of, v.n_roots, np.dtype("<u4"))}
+                "root_of": _view(v.root_of, v.n_roots, np.dtype("<u4")),
+                "gate_next": _view(v.gate_next, v.n_roots, np.dtype("<u4"))}
     finally:
         lib.rt_accel_free(C.byref(v))
 

@@ -2,13 +2,22 @@
 //
 // The reference keeps every shape that straddles a split plane in the INNER group of its
 // `divide` tree (groups.rs:198-299), so a ray that enters a group tests all of that group's own
-// shapes linearly (groups.rs:118-120).  For the ~871 k-triangle dragon that is thousands of
-// Möller–Trumbore tests per ray.  The device scene keeps the reference tree verbatim (its box
-// tests decide what the reference would have tested — SURVEY.md Q6/Q7), and hangs one *auxiliary*
-// BVH under every group whose own shapes are many identity-transform triangles.  The auxiliary
-// BVH only skips triangles whose test could not have succeeded, so the set of intersections found
-// — and with it min(t, rank) and the n1/n2 list — is unchanged (DESIGN.md "Auxiliary BVH":
-// padding rule, per-ray guard, and the ACCEL == NO_ACCEL full-frame test).
+// shapes linearly (groups.rs:118-120), and it re-tests one bounding box per tree level.  For the
+// ~871 k-triangle dragon that is thousands of Möller–Trumbore tests per ray.
+//
+// The device scene keeps the reference tree verbatim, and for every maximal subtree that consists
+// only of identity-transform groups holding identity-transform triangles (what `divide` makes of an
+// OBJ group) it adds ONE auxiliary BVH over all triangles of the subtree.  A ray that reaches the
+// subtree root R (R's own box test is still the reference's) traverses the auxiliary BVH instead of
+// the subtree.  Two rules keep the result identical to the reference's (DESIGN.md "Auxiliary BVH"):
+//   1. culling is conservative: boxes are widened per ray by more than the f32 slop of the
+//      reference's triangle test, so only triangles that test would reject are skipped;
+//   2. a triangle the test accepts still counts only if the reference would have REACHED it, i.e.
+//      if the box test of its owning group G and of every group between G and R passes
+//      (groups.rs:111-113).  Inside such a subtree boxes are unions of their contents
+//      (groups.rs:176-188), so they nest, and for nested finite boxes "G passes" implies "every
+//      ancestor passes" (monotonicity of the correctly rounded slab arithmetic, for rays with at
+//      least one |d| >= 1e-4 component).  gate_next[] lists the groups whose test is NOT implied.
 //
 // Layout (device, 64 B per node, 16 B aligned):
 //   aux[root]      header: {cx, cy, cz, radius} {lmax, amax, 0, 0} {unused} {unused}
@@ -16,8 +25,8 @@
 //   aux[root + 1]  top node; every node holds the boxes of BOTH children:
 //     {lmin.xyz, left}  {lmax.xyz, lcount}  {rmin.xyz, right}  {rmax.xyz, rcount}
 //     count == 0: child is the node aux[left]; count > 0: child is the leaf
-//     aux_tris[left .. left+count), 3 float4 per triangle: {p1.xyz, k} {e1.xyz, 0} {e2.xyz, 0}
-//     where k (uint bits) is the triangle's offset inside its group: shape = first_shape + k.
+//     aux_tris[left .. left+count), 3 float4 per triangle:
+//       {p1.xyz, shape index} {e1.xyz, owning node index} {e2.xyz, 0}      (indices as uint bits)
 #pragma once
 
 #include <algorithm>
@@ -32,7 +41,7 @@
 namespace rtaccel {
 
 constexpr uint32_t kNone = 0xFFFFFFFFu;
-constexpr uint32_t kMinTris = 12;    // groups with fewer own triangles keep the linear loop
+constexpr uint32_t kMinTris = 12;    // subtrees with fewer triangles keep the reference walk
 constexpr uint32_t kLeafTris = 4;    // max triangles per leaf
 constexpr int kMaxDepth = 22;        // device stack holds kMaxDepth + 2 entries
 constexpr float kPadRel = 0.01f;     // static box padding relative to the triangle's largest extent
@@ -51,53 +60,91 @@ struct Node {
 static_assert(sizeof(Node) == 64, "aux node is 64 B");
 struct Tri {
   float p1[3];
-  uint32_t k;
-  float e1[3], pad1;
-  float e2[3], pad2;
+  uint32_t shape;
+  float e1[3];
+  uint32_t owner;
+  float e2[3];
+  uint32_t pad;
 };
 static_assert(sizeof(Tri) == 48, "aux triangle is 48 B");
 
 struct Result {
-  std::vector<Node> nodes;       // all trees back to back
-  std::vector<Tri> tris;         // leaf triangles in leaf order
-  std::vector<uint32_t> root_of; // per reference node: header index or kNone
+  std::vector<Node> nodes;         // all trees back to back
+  std::vector<Tri> tris;           // leaf triangles in leaf order
+  std::vector<uint32_t> root_of;   // per reference node: header index of the subtree's BVH (roots only) or kNone
+  std::vector<uint32_t> gate_next; // per reference node inside a subtree: next group whose box test is not implied
 };
 
 struct Item {
   float lo[3], hi[3], c[3];
-  uint32_t k;
+  uint32_t tri;    // index into RtScene::tri_geom
+  uint32_t shape;  // index into RtScene::shapes
+  uint32_t owner;  // node index
 };
 
 struct TreeBuilder {
-  const RtTriGeom* geom;  // geometry of the group's triangles (first_tri based)
+  const RtTriGeom* geom = nullptr;  // RtScene::tri_geom
   std::vector<Item> items;
   std::vector<Node> nodes;  // local; [0] header, [1] top
   std::vector<Tri> tris;
   float lmax = 0.f, amax = 0.f;
   int depth_seen = 0;
+  float blo[3] = {INFINITY, INFINITY, INFINITY}, bhi[3] = {-INFINITY, -INFINITY, -INFINITY};
 
-  static void merge(float* lo, float* hi, const Item& it) {
+  bool add(uint32_t tri, uint32_t shape, uint32_t owner) {
+    const RtTriGeom& g = geom[tri];
+    Item it;
+    it.tri = tri, it.shape = shape, it.owner = owner;
+    float ext = 0.f, mag = 0.f;
     for (int a = 0; a < 3; a++) {
-      lo[a] = std::min(lo[a], it.lo[a]);
-      hi[a] = std::max(hi[a], it.hi[a]);
+      float p1 = g.p1[a], p2 = p1 + g.e1[a], p3 = p1 + g.e2[a];
+      if (!std::isfinite(p1) || !std::isfinite(p2) || !std::isfinite(p3)) return false;
+      it.lo[a] = std::min(p1, std::min(p2, p3));
+      it.hi[a] = std::max(p1, std::max(p2, p3));
+      ext = std::max(ext, it.hi[a] - it.lo[a]);
+      mag = std::max(mag, std::max(std::fabs(it.lo[a]), std::fabs(it.hi[a])));
     }
+    float l1 = 0.f, l2 = 0.f, l3 = 0.f;
+    for (int a = 0; a < 3; a++) {
+      float d = g.e2[a] - g.e1[a];
+      l1 += g.e1[a] * g.e1[a], l2 += g.e2[a] * g.e2[a], l3 += d * d;
+    }
+    float edge = std::sqrt(std::max(l1, std::max(l2, l3)));
+    lmax = std::max(lmax, edge);
+    amax = std::max(amax, std::sqrt(l1) * std::sqrt(l2) * 1.000001f);
+    float pad = kPadRel * std::max(ext, edge) + kPadAbs * mag + 1e-30f;
+    for (int a = 0; a < 3; a++) {
+      it.lo[a] -= pad;
+      it.hi[a] += pad;
+      it.c[a] = 0.5f * (it.lo[a] + it.hi[a]);
+      blo[a] = std::min(blo[a], it.lo[a]);
+      bhi[a] = std::max(bhi[a], it.hi[a]);
+    }
+    items.push_back(it);
+    return true;
   }
-  // returns child reference for [b,e): (index, count); writes the box
+
+  // child reference for [b,e): (index, count) and its box
   void build(uint32_t b, uint32_t e, int depth, uint32_t* ref, uint32_t* count, float* lo, float* hi) {
     depth_seen = std::max(depth_seen, depth);
     for (int a = 0; a < 3; a++) lo[a] = INFINITY, hi[a] = -INFINITY;
-    for (uint32_t i = b; i < e; i++) merge(lo, hi, items[i]);
+    for (uint32_t i = b; i < e; i++)
+      for (int a = 0; a < 3; a++) {
+        lo[a] = std::min(lo[a], items[i].lo[a]);
+        hi[a] = std::max(hi[a], items[i].hi[a]);
+      }
     uint32_t n = e - b;
     if (n <= kLeafTris) {
       *ref = (uint32_t)tris.size();
       *count = n;
       for (uint32_t i = b; i < e; i++) {
-        const RtTriGeom& g = geom[items[i].k];
+        const RtTriGeom& g = geom[items[i].tri];
         Tri t{};
         std::memcpy(t.p1, g.p1, 12);
         std::memcpy(t.e1, g.e1, 12);
         std::memcpy(t.e2, g.e2, 12);
-        t.k = items[i].k;
+        t.shape = items[i].shape;
+        t.owner = items[i].owner;
         tris.push_back(t);
       }
       return;
@@ -114,7 +161,7 @@ struct TreeBuilder {
       if (chi[a] - clo[a] > chi[axis] - clo[axis]) axis = a;
     uint32_t mid = b + n / 2;
     std::nth_element(items.begin() + b, items.begin() + mid, items.begin() + e, [axis](const Item& x, const Item& y) {
-      return x.c[axis] < y.c[axis] || (x.c[axis] == y.c[axis] && x.k < y.k);
+      return x.c[axis] < y.c[axis] || (x.c[axis] == y.c[axis] && x.shape < y.shape);
     });
     uint32_t me = (uint32_t)nodes.size();
     nodes.emplace_back();
@@ -126,40 +173,10 @@ struct TreeBuilder {
     nodes[me] = nd;
   }
 
-  // false: this group keeps the linear loop
-  bool run(const RtTriGeom* g, uint32_t n) {
-    geom = g;
-    items.resize(n);
-    float blo[3] = {INFINITY, INFINITY, INFINITY}, bhi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (uint32_t k = 0; k < n; k++) {
-      Item& it = items[k];
-      it.k = k;
-      float ext = 0.f, mag = 0.f, edge = 0.f;
-      for (int a = 0; a < 3; a++) {
-        float p1 = g[k].p1[a], p2 = p1 + g[k].e1[a], p3 = p1 + g[k].e2[a];
-        if (!std::isfinite(p1) || !std::isfinite(p2) || !std::isfinite(p3)) return false;
-        it.lo[a] = std::min(p1, std::min(p2, p3));
-        it.hi[a] = std::max(p1, std::max(p2, p3));
-        ext = std::max(ext, it.hi[a] - it.lo[a]);
-        mag = std::max(mag, std::max(std::fabs(it.lo[a]), std::fabs(it.hi[a])));
-      }
-      float l1 = 0.f, l2 = 0.f, l3 = 0.f;
-      for (int a = 0; a < 3; a++) {
-        float d = g[k].e2[a] - g[k].e1[a];
-        l1 += g[k].e1[a] * g[k].e1[a], l2 += g[k].e2[a] * g[k].e2[a], l3 += d * d;
-      }
-      edge = std::sqrt(std::max(l1, std::max(l2, l3)));
-      lmax = std::max(lmax, edge);
-      amax = std::max(amax, std::sqrt(l1) * std::sqrt(l2) * 1.000001f);
-      float pad = kPadRel * std::max(ext, edge) + kPadAbs * mag + 1e-30f;
-      for (int a = 0; a < 3; a++) {
-        it.lo[a] -= pad;
-        it.hi[a] += pad;
-        it.c[a] = 0.5f * (it.lo[a] + it.hi[a]);
-        blo[a] = std::min(blo[a], it.lo[a]);
-        bhi[a] = std::max(bhi[a], it.hi[a]);
-      }
-    }
+  // false: this subtree keeps the reference walk
+  bool finish() {
+    uint32_t n = (uint32_t)items.size();
+    if (n < kMinTris) return false;
     nodes.clear();
     tris.clear();
     tris.reserve(n);
@@ -184,29 +201,58 @@ struct TreeBuilder {
   }
 };
 
+inline bool box_finite(const RtNode& n) {
+  for (int a = 0; a < 3; a++)
+    if (!std::isfinite(n.bmin[a]) || !std::isfinite(n.bmax[a])) return false;
+  return true;
+}
+inline bool box_inside(const RtNode& c, const RtNode& p) {
+  for (int a = 0; a < 3; a++)
+    if (!(c.bmin[a] >= p.bmin[a] && c.bmax[a] <= p.bmax[a])) return false;
+  return true;
+}
+
 inline Result build(const RtScene* s) {
   Result r;
-  r.root_of.assign(s->n_nodes, kNone);
-  std::vector<uint32_t> todo;
-  for (uint32_t i = 0; i < s->n_nodes; i++) {
+  const uint32_t nn = s->n_nodes;
+  r.root_of.assign(nn, kNone);
+  r.gate_next.assign(nn, kNone);
+  if (nn == 0) return r;
+  // sub_ok[i]: node i and everything below it are identity-transform groups (i itself may carry a
+  // transform) whose own shapes are identity-transform triangles, with finite boxes.
+  std::vector<uint8_t> sub_ok(nn, 0);
+  for (uint32_t i = nn; i-- > 0;) {
     const RtNode& n = s->nodes[i];
-    if ((n.flags & RT_NODE_ALL_TRIS) && n.n_shapes >= kMinTris) todo.push_back(i);
+    bool ok = (n.n_shapes == 0 || (n.flags & RT_NODE_ALL_TRIS)) && box_finite(n);
+    for (uint32_t c = i + 1; ok && c < n.skip; c = s->nodes[c].skip)  // direct children
+      ok = sub_ok[c] && s->nodes[c].xform == 0;
+    sub_ok[i] = ok;
   }
-  if (todo.empty()) return r;
-  // build the trees in parallel, then concatenate with rebased indices
+  std::vector<uint32_t> roots;
+  for (uint32_t i = 0; i < nn; i++) {
+    const RtNode& n = s->nodes[i];
+    bool inside_parent = n.parent >= 0 && sub_ok[n.parent] && n.xform == 0;
+    if (sub_ok[i] && !inside_parent) roots.push_back(i);
+  }
   struct Out {
     std::vector<Node> nodes;
     std::vector<Tri> tris;
     bool ok = false;
   };
-  std::vector<Out> outs(todo.size());
+  std::vector<Out> outs(roots.size());
   unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-  if (todo.size() < 64) nt = 1;
+  if (roots.size() < 2) nt = 1;
   auto work = [&](unsigned t) {
-    for (size_t j = t; j < todo.size(); j += nt) {
-      const RtNode& n = s->nodes[todo[j]];
+    for (size_t j = t; j < roots.size(); j += nt) {
+      uint32_t R = roots[j];
       TreeBuilder tb;
-      outs[j].ok = tb.run(s->tri_geom + n.first_tri, n.n_shapes);
+      tb.geom = s->tri_geom;
+      bool ok = true;
+      for (uint32_t i = R; ok && i < s->nodes[R].skip; i++) {
+        const RtNode& n = s->nodes[i];
+        for (uint32_t k = 0; ok && k < n.n_shapes; k++) ok = tb.add(n.first_tri + k, n.first_shape + k, i);
+      }
+      outs[j].ok = ok && tb.finish();
       if (outs[j].ok) {
         outs[j].nodes = std::move(tb.nodes);
         outs[j].tris = std::move(tb.tris);
@@ -217,11 +263,12 @@ inline Result build(const RtScene* s) {
   for (unsigned t = 1; t < nt; t++) th.emplace_back(work, t);
   work(0);
   for (auto& t : th) t.join();
-  for (size_t j = 0; j < todo.size(); j++) {
+  for (size_t j = 0; j < roots.size(); j++) {
     if (!outs[j].ok) continue;
     uint64_t nb = r.nodes.size(), tbase = r.tris.size();
     if (nb + outs[j].nodes.size() >= 0x1FFFFFFFull || tbase + outs[j].tris.size() >= 0x1FFFFFFFull) break;
-    r.root_of[todo[j]] = (uint32_t)nb;
+    uint32_t R = roots[j];
+    r.root_of[R] = (uint32_t)nb;
     for (size_t q = 0; q < outs[j].nodes.size(); q++) {
       Node nd = outs[j].nodes[q];
       if (q > 0) {
@@ -231,6 +278,17 @@ inline Result build(const RtScene* s) {
       r.nodes.push_back(nd);
     }
     r.tris.insert(r.tris.end(), outs[j].tris.begin(), outs[j].tris.end());
+    // gate chains: gate_next[c] = nearest proper ancestor A below R whose test is not implied by the
+    // tests already made on the way up, i.e. the node just below A on the path is not nested in A.
+    for (uint32_t c = R + 1; c < s->nodes[R].skip; c++) {
+      uint32_t p = (uint32_t)s->nodes[c].parent;
+      if (p == R)
+        r.gate_next[c] = kNone;
+      else if (box_inside(s->nodes[c], s->nodes[p]))
+        r.gate_next[c] = r.gate_next[p];
+      else
+        r.gate_next[c] = p;
+    }
   }
   return r;
 }

@@ -17,8 +17,11 @@
 #define RT_CSG_DEPTH 8       // csg tree depth
 #define RT_XS_CAP 96         // per-ray entries for the n1/n2 container walk
 #define RT_AUX_STACK 24      // per-lane auxiliary-BVH stack entries, kept in LDS (rt_accel.h kMaxDepth + 2)
-#define RT_BLOCK 256         // every kernel that traces runs 256-thread blocks (LDS stack stride)
+#ifndef RT_BLOCK
+#define RT_BLOCK 256         // threads per block of every kernel that traces (LDS stack stride): 256 or 64
+#endif
 #define RT_AUX_NONE 0xFFFFFFFFu
+#define RT_NODE_AUX 0x4u      // device copy only: this node is the root of a subtree covered by an auxiliary BVH
 
 namespace rtd {
 
@@ -54,7 +57,7 @@ __device__ __forceinline__ float of_min(float a, float b) { return of_gt(a, b) ?
 struct Counters {
   uint32_t primary, shadow, reflect, refract, overflow;
   // work counters (only maintained by the COUNT instantiations; bench roofline)
-  uint32_t node_visits, tri_tests, shape_tests, shaded, xforms;
+  uint32_t node_visits, tri_tests, shape_tests, shaded, xforms, aux_tests;
 };
 
 struct Scene {
@@ -297,38 +300,46 @@ __device__ __forceinline__ void load_tri(const Scene& sc, uint32_t prim, V3& p1,
 }
 
 // ---------------------------------------------------------------------------------------
-// Sinks: what a traversal does with each intersection it finds.
+// Sink: what a traversal does with each intersection it finds.  One type with two modes, so that
+// the traversal code exists once in the kernel (instruction-cache footprint, DESIGN.md "Kernel").
+//  closest: Intersections::hit() (intersections.rs:94-96) over the stable t-sorted list (SURVEY.md
+//           Q1): minimise (t, insertion rank) over t > 0.  Traversal order is therefore free.
+//  collect: every intersection with t <= tlimit (total order), for the n1/n2 container walk.
 // ---------------------------------------------------------------------------------------
-// Intersections::hit() (intersections.rs:94-96) over the stable t-sorted list:
-// minimise (t, insertion rank) over t > 0.  Traversal order is therefore free.
-struct ClosestSink {
+struct Sink {
   float t, u, v;
   int shape;
-  __device__ __forceinline__ void init() {
-    t = __builtin_inff();
-    u = v = 0.f;
-    shape = -1;
-  }
-  __device__ __forceinline__ void add(float tt, uint32_t s, float uu, float vv) {
-    if (tt > 0.f && (shape < 0 || tt < t || (tt == t && (int)s < shape))) {
-      t = tt;
-      shape = (int)s;
-      u = uu;
-      v = vv;
-    }
-  }
-  __device__ __forceinline__ float limit() const { return shape < 0 ? __builtin_inff() : t; }
-  static constexpr bool wants_negative = false;
-};
-// Every intersection with t <= tlimit (total order), for the n1/n2 container walk.
-struct CollectSink {
   float* ts;
   uint32_t* ss;
   int n;
   int overflow;
   float tlimit;
-  __device__ __forceinline__ void add(float tt, uint32_t s, float, float) {
-    if (!of_gt(tt, tlimit)) {
+  bool collect;
+  __device__ __forceinline__ void init_closest() {
+    t = __builtin_inff();
+    u = v = 0.f;
+    shape = -1;
+    ts = nullptr;
+    ss = nullptr;
+    n = 0;
+    overflow = 0;
+    tlimit = 0.f;
+    collect = false;
+  }
+  __device__ __forceinline__ void init_collect(float* ts_, uint32_t* ss_, float tlimit_) {
+    init_closest();
+    ts = ts_;
+    ss = ss_;
+    tlimit = tlimit_;
+    collect = true;
+  }
+  __device__ __forceinline__ bool wants(float tt, uint32_t s) const {
+    if (collect) return !of_gt(tt, tlimit);
+    return tt > 0.f && (shape < 0 || tt < t || (tt == t && (int)s < shape));
+  }
+  __device__ __forceinline__ void add(float tt, uint32_t s, float uu, float vv) {
+    if (!wants(tt, s)) return;
+    if (collect) {
       if (n < RT_XS_CAP) {
         ts[n] = tt;
         ss[n] = s;
@@ -336,10 +347,15 @@ struct CollectSink {
       } else {
         overflow = 1;
       }
+    } else {
+      t = tt;
+      shape = (int)s;
+      u = uu;
+      v = vv;
     }
   }
-  __device__ __forceinline__ float limit() const { return tlimit; }
-  static constexpr bool wants_negative = true;
+  __device__ __forceinline__ float limit() const { return collect ? tlimit : (shape < 0 ? __builtin_inff() : t); }
+  __device__ __forceinline__ bool wants_negative() const { return collect; }
 };
 
 // Shape::intersect (shapes.rs:204-246): inverse-transform the ray, dispatch on kind.
@@ -477,24 +493,14 @@ __device__ inline void csg_eval(const Scene& sc, RtCsgRoot root, const Ray& ray,
 }
 
 // ---------------------------------------------------------------------------------------
-// Auxiliary BVH under a group whose own shapes are many identity-transform triangles
-// (rt_accel.h).  Same Möller–Trumbore arithmetic on the same triangles as the reference's
-// linear loop (groups.rs:118-120); the BVH only skips triangles the test would have rejected.
+// Auxiliary BVH over a whole subtree of identity-transform triangle groups (rt_accel.h).  Same
+// Möller–Trumbore arithmetic on the same triangles as the reference's linear loops
+// (groups.rs:118-120); the BVH only skips triangles the test would have rejected, and an accepted
+// triangle is kept only if the reference's own box tests would have let the ray reach it.
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t* aux_stack() {
   __shared__ uint32_t stk[RT_AUX_STACK * RT_BLOCK];
   return stk + threadIdx.x;
-}
-template <bool COUNT, class Sink>
-__device__ __forceinline__ void tris_linear(const Scene& sc, uint32_t first_shape, uint32_t first_tri, uint32_t n,
-                                            const Ray& cur, Sink& sink, Counters& cn) {
-  if (COUNT) cn.tri_tests += n;
-  for (uint32_t k = 0; k < n; k++) {
-    V3 p1, e1, e2;
-    load_tri(sc, first_tri + k, p1, e1, e2);
-    float t, u, v;
-    if (isect_triangle(cur, p1, e1, e2, t, u, v)) sink.add(t, first_shape + k, u, v);
-  }
 }
 // Conservative slab test against a box widened by `pad`: never reports a miss for a line that comes
 // within the padding of the box contents; NaNs (0 * inf) count as "inside".
@@ -510,10 +516,30 @@ __device__ __forceinline__ bool aux_box(V3 o, V3 inv, float pad, float4 mn, floa
   tnear = tn;
   return !(tn > tf) && !(tn > hi) && !(tf < lo);
 }
-template <bool COUNT, class Sink>
-__device__ inline void aux_intersect(const Scene& sc, uint32_t root, uint32_t first_shape, uint32_t first_tri,
-                                     uint32_t n_shapes, const Ray& cur, Sink& sink, Counters& cn) {
-  const float4* A = sc.aux_nodes + 4u * (size_t)root;
+// Would the reference have reached the shapes of group `g` from the subtree root `root`?  The box test
+// of g, then of every group on the way up whose test is not implied by nesting (rt_accel.h gate_next).
+template <bool COUNT>
+__device__ __forceinline__ bool aux_gate(const Scene& sc, uint32_t g, uint32_t root, const Ray& cur, Counters& cn) {
+  while (g != root && g != RT_AUX_NONE) {
+    const uint4* raw = reinterpret_cast<const uint4*>(sc.nodes + g);
+    uint4 w0 = raw[0], w1 = raw[1], w3 = raw[3];
+    if (COUNT) cn.node_visits++;
+    float tmin, tmax;
+    V3 bmin = v3(__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z));
+    V3 bmax = v3(__uint_as_float(w1.x), __uint_as_float(w1.y), __uint_as_float(w1.z));
+    if (!slab(cur, bmin, bmax, tmin, tmax)) return false;  // groups.rs:111-113
+    g = w3.w;
+  }
+  return true;
+}
+// false: this ray must take the reference walk through the subtree (nothing has been added to the sink)
+template <bool COUNT>
+__device__ inline bool aux_intersect(const Scene& sc, uint32_t root_node, uint32_t aux_root, const Ray& cur, Sink& sink,
+                                     Counters& cn) {
+  // the nesting argument behind aux_gate needs one axis on the non-parallel branch of check_axis
+  if (!(__builtin_fabsf(cur.d.x) >= 1e-4f || __builtin_fabsf(cur.d.y) >= 1e-4f || __builtin_fabsf(cur.d.z) >= 1e-4f))
+    return false;
+  const float4* A = sc.aux_nodes + 4u * (size_t)aux_root;
   float4 h0 = A[0], h1 = A[1];
   // Ray-dependent widening (DESIGN.md "Auxiliary BVH"): in f32 the reference's triangle test accepts a
   // line that passes the triangle's plane up to 16u * K * (|s| + L) outside it (u = 2^-24,
@@ -524,24 +550,21 @@ __device__ inline void aux_intersect(const Scene& sc, uint32_t root, uint32_t fi
   float S = magnitude(oc) + h0.w;
   float dm = magnitude(cur.d);
   float pad = (0.0143f * h1.y) * (dm * (S + h1.x));
-  if (!(pad < h0.w)) {  // NaN/inf, or wider than the whole tree: the linear loop is the better (and exact) choice
-    tris_linear<COUNT>(sc, first_shape, first_tri, n_shapes, cur, sink, cn);
-    return;
-  }
+  if (!(pad < h0.w)) return false;  // NaN/inf, or wider than the whole tree
   V3 inv = v3(__builtin_amdgcn_rcpf(cur.d.x), __builtin_amdgcn_rcpf(cur.d.y), __builtin_amdgcn_rcpf(cur.d.z));
   uint32_t* stk = aux_stack();
   int sp = 0;
-  uint32_t ref = (root + 1u) << 3;
+  uint32_t ref = (aux_root + 1u) << 3;
   // the computed t of an accepted hit lies within 13u * K * |s| / |d| < 0.55 * pad / |d| of the line's true
   // crossing of the triangle's plane, which is inside the widened box: slack for the t-range pruning
   const float tpad = pad / dm;
-  const float lo = (Sink::wants_negative ? -__builtin_inff() : 0.f) - tpad;
+  const float lo = (sink.wants_negative() ? -__builtin_inff() : 0.f) - tpad;
   while (true) {
     uint32_t cnt = ref & 7u, idx = ref >> 3;
     if (cnt == 0u) {
       const float4* N = sc.aux_nodes + 4u * (size_t)idx;
       float4 n0 = N[0], n1 = N[1], n2 = N[2], n3 = N[3];
-      if (COUNT) cn.node_visits += 2;
+      if (COUNT) cn.aux_tests += 2;
       float lim = sink.limit();
       float hi = (lim + 1e-5f * __builtin_fabsf(lim)) + tpad;
       float tl, tr;
@@ -566,24 +589,51 @@ __device__ inline void aux_intersect(const Scene& sc, uint32_t root, uint32_t fi
       for (uint32_t k = 0; k < cnt; k++) {
         float4 a = T[3 * k], b = T[3 * k + 1], c = T[3 * k + 2];
         float t, u, v;
-        if (isect_triangle(cur, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), v3(c.x, c.y, c.z), t, u, v))
-          sink.add(t, first_shape + __float_as_uint(a.w), u, v);
+        if (isect_triangle(cur, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), v3(c.x, c.y, c.z), t, u, v)) {
+          uint32_t shape = __float_as_uint(a.w);
+          if (sink.wants(t, shape) && aux_gate<COUNT>(sc, __float_as_uint(b.w), root_node, cur, cn))
+            sink.add(t, shape, u, v);
+        }
       }
     }
     if (sp == 0) break;
     ref = stk[(--sp) * RT_BLOCK];
   }
+  return true;
 }
 
 // ---------------------------------------------------------------------------------------
 // World::intersect (world.rs:44-62) as one traversal feeding a sink.
 // Groups: stackless depth-first walk over the DFS-ordered node array (skip pointers); the ray is
-// re-expressed in a group's space when the group has a non-identity transform (groups.rs:127-133)
-// and restored when the walk leaves that subtree.
+// re-expressed in a group's space when the group has a non-identity transform (groups.rs:127-133).
+// No per-lane stack of saved rays: when the walk leaves a transformed subtree, the ray of the next
+// node's space is rebuilt from the world ray through that node's chain of transformed ancestors
+// (same matrices in the same order => same bits).
 // ---------------------------------------------------------------------------------------
-template <bool COUNT, class Sink>
+__device__ inline Ray ray_in_space_of(const Scene& sc, int xf_node, const Ray& world) {
+  // xf_node: innermost transformed group whose space is wanted (-1 = world)
+  int chain[RT_MAX_XF_DEPTH];
+  int n = 0;
+  int q = xf_node;
+  while (q >= 0 && n < RT_MAX_XF_DEPTH) {
+    chain[n++] = q;
+    int par = sc.nodes[q].parent;
+    q = par >= 0 ? sc.nodes[par].next_xf : -1;
+  }
+  Ray r = world;
+  for (int k = n - 1; k >= 0; k--) r = xf_ray(sc, sc.nodes[chain[k]].xform, r);
+  return r;
+}
+// The walk is WAVE-SYNCHRONOUS: every lane walks the same DFS order and lanes differ only in the
+// subtrees they skip, so the node index is kept uniform across the wave (all node, transform, shape and
+// triangle records of the reference tree are then fetched with scalar loads, off the vector-memory
+// path that the divergent auxiliary-BVH fetches need), and a lane takes part in a visit only when the
+// node is the one it is waiting for.  After node i, a visiting lane waits for i+1 or for skip(i); lanes
+// that sat the visit out wait for something >= skip(i); so the next uniform index is i+1 if any lane
+// descends and skip(i) otherwise.
+__device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+template <bool COUNT>
 __device__ inline void world_intersect(const Scene& sc, const Ray& ray, Sink& sink, Counters& cn) {
-  int csg_overflow = 0;
   // csgs first (world.rs:45-49)
   if (sc.n_csg_roots) {
     CsgList L;
@@ -592,62 +642,71 @@ __device__ inline void world_intersect(const Scene& sc, const Ray& ray, Sink& si
       csg_eval(sc, sc.csg_roots[c], ray, L);
       for (int i = 0; i < L.n; i++) sink.add(L.t[i], L.s[i], __builtin_nanf(""), __builtin_nanf(""));
     }
-    csg_overflow |= L.overflow;
+    cn.overflow += L.overflow;
   }
-  cn.overflow += csg_overflow;
   // groups (world.rs:51-54)
   {
-    Ray saved[RT_MAX_XF_DEPTH];
-    uint32_t restore_at[RT_MAX_XF_DEPTH];
-    int rs = 0;
     Ray cur = ray;
+    uint32_t leave_at = 0xFFFFFFFFu;  // first node outside the innermost transformed subtree this lane is in
     const bool prune = !(sc.flags & RT_RENDER_NO_PRUNE);
-    uint32_t i = 0;
+    uint32_t my_i = 0;                // the node this lane visits next
+    uint32_t i = 0;                   // wave-uniform
     while (i < sc.n_nodes) {
-      while (rs > 0 && i >= restore_at[rs - 1]) cur = saved[--rs];
+      i = __builtin_amdgcn_readfirstlane(i);
       const uint4* raw = reinterpret_cast<const uint4*>(sc.nodes + i);
       uint4 w0 = raw[0], w1 = raw[1], w2 = raw[2], w3 = raw[3];
-      uint32_t xform = w0.w, flags = w1.w, skip = w2.z;
-      if (COUNT) cn.node_visits++;
-      if (COUNT && xform) cn.xforms++;
-      if (xform) {
-        saved[rs] = cur;
-        restore_at[rs] = skip;
-        rs++;
-        cur = xf_ray(sc, xform, cur);
-      }
-      float tmin, tmax;
-      V3 bmin = v3(__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z));
-      V3 bmax = v3(__uint_as_float(w1.x), __uint_as_float(w1.y), __uint_as_float(w1.z));
-      if (!slab(cur, bmin, bmax, tmin, tmax)) {  // groups.rs:111-113
-        i = skip;
-        continue;
-      }
-      if (prune && (flags & RT_NODE_PRUNABLE)) {
-        // Distance pruning (not in the reference): a box that truly encloses its subtree cannot
-        // hold a hit beyond its exit or before its entry; margins cover f32 rounding of t.
-        float lim = sink.limit();
-        if (tmin > lim + (1e-4f * __builtin_fabsf(lim) + 1e-4f)) {
-          i = skip;
-          continue;
+      const uint32_t xform = w0.w, flags = w1.w, skip = w2.z;
+      bool descend = false;
+      if (my_i == i) {
+        if (i >= leave_at) {
+          int par = (int)w2.w;
+          int q = par >= 0 ? sc.nodes[par].next_xf : -1;
+          cur = q >= 0 ? ray_in_space_of(sc, q, ray) : ray;
+          leave_at = q >= 0 ? sc.nodes[q].skip : 0xFFFFFFFFu;
         }
-        if (!Sink::wants_negative && tmax < -(1e-4f * __builtin_fabsf(tmax) + 1e-4f)) {
-          i = skip;
-          continue;
+        if (COUNT) cn.node_visits++;
+        if (COUNT && xform) cn.xforms++;
+        if (xform) {
+          cur = xf_ray(sc, xform, cur);
+          leave_at = skip;
         }
+        float tmin, tmax;
+        V3 bmin = v3(__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z));
+        V3 bmax = v3(__uint_as_float(w1.x), __uint_as_float(w1.y), __uint_as_float(w1.z));
+        descend = slab(cur, bmin, bmax, tmin, tmax);  // groups.rs:111-113
+        if (descend && prune && (flags & RT_NODE_PRUNABLE)) {
+          // Distance pruning (not in the reference): a box that truly encloses its subtree cannot
+          // hold a hit beyond its exit or before its entry; margins cover f32 rounding of t.
+          float lim = sink.limit();
+          if (tmin > lim + (1e-4f * __builtin_fabsf(lim) + 1e-4f)) descend = false;
+          if (!sink.wants_negative() && tmax < -(1e-4f * __builtin_fabsf(tmax) + 1e-4f)) descend = false;
+        }
+        // device copy of a node: the slot of n_children holds the auxiliary BVH of the subtree (RT_NODE_AUX)
+        if (descend && (flags & RT_NODE_AUX) && !(sc.flags & RT_RENDER_NO_ACCEL) &&
+            aux_intersect<COUNT>(sc, i, w3.w, cur, sink, cn))
+          descend = false;
       }
-      uint32_t first_shape = w2.x, n_shapes = w2.y;
-      if (flags & RT_NODE_ALL_TRIS) {
-        uint32_t first_tri = w3.x, aux = w3.w;  // device copy: n_children is replaced by the aux root
-        if (aux != RT_AUX_NONE && !(sc.flags & RT_RENDER_NO_ACCEL))
-          aux_intersect<COUNT>(sc, aux, first_shape, first_tri, n_shapes, cur, sink, cn);
-        else
-          tris_linear<COUNT>(sc, first_shape, first_tri, n_shapes, cur, sink, cn);
+      if (wave_any(descend)) {
+        const uint32_t first_shape = w2.x, n_shapes = w2.y;
+        if (flags & RT_NODE_ALL_TRIS) {
+          if (COUNT && descend) cn.tri_tests += n_shapes;
+          for (uint32_t k = 0; k < n_shapes; k++) {
+            V3 p1, e1, e2;
+            load_tri(sc, w3.x + k, p1, e1, e2);
+            float t, u, v;
+            if (descend && isect_triangle(cur, p1, e1, e2, t, u, v)) sink.add(t, first_shape + k, u, v);
+          }
+        } else {
+          if (COUNT && descend) cn.shape_tests += n_shapes;
+          for (uint32_t k = 0; k < n_shapes; k++)
+            if (descend) shape_intersect(sc, first_shape + k, cur, sink);
+        }
+        if (my_i == i) my_i = descend ? i + 1u : skip;
+        i = i + 1u;
       } else {
-        if (COUNT) cn.shape_tests += n_shapes;
-        for (uint32_t k = 0; k < n_shapes; k++) shape_intersect(sc, first_shape + k, cur, sink);
+        if (my_i == i) my_i = skip;
+        i = skip;
       }
-      i = i + 1;
     }
   }
   // loose shapes (world.rs:56-59): the last n_loose entries of shapes[]
@@ -885,27 +944,6 @@ struct Hit {
   int shape;
 };
 
-// Intersections::hit() of World::intersect(ray).
-template <bool COUNT>
-__device__ inline Hit trace_closest(const Scene& sc, const Ray& ray, Counters& cn) {
-  ClosestSink sink;
-  sink.init();
-  world_intersect<COUNT>(sc, ray, sink, cn);
-  return Hit{sink.t, sink.u, sink.v, sink.shape};
-}
-
-// World::is_shadowed (world.rs:101-111): closest-hit semantics.
-template <bool COUNT>
-__device__ inline bool is_shadowed(const Scene& sc, V3 light_position, V3 p, Counters& cn) {
-  V3 v = light_position - p;
-  float distance = magnitude(v);
-  V3 direction = v / distance;
-  cn.shadow++;
-  Hit h = trace_closest<COUNT>(sc, Ray{p, direction}, cn);
-  if (h.shape < 0) return false;
-  return h.t < distance && (sc.shapes[h.shape].kind_flags & RT_SHAPE_SHADOW);
-}
-
 __device__ __forceinline__ V3 point_on_light(const RtLight& l, uint32_t li, uint32_t u, uint32_t v, uint32_t site,
                                              const RenderParams& rp, uint32_t pixel, uint32_t path) {
   float ju, jv;
@@ -940,33 +978,40 @@ __device__ __forceinline__ bool phong_sample(V3 light_pos, V3 pt, V3 eyev, V3 no
   return true;
 }
 
+// ---------------------------------------------------------------------------------------
+// World::color_at (world.rs:91-99) as a per-lane job loop around ONE traversal call site.
+// The reference recursion  color_at -> shade_hit -> {is_shadowed per light sample, reflected_color,
+// refracted_color -> color_at}  (world.rs:64-148) becomes a state machine: every iteration traces
+// one ray (a primary/secondary ray, a shadow ray of the current light sample, or the n1/n2 collect
+// pass of a transparent hit) and then advances the shading state.  Lanes of a wave therefore trace
+// together whatever kind of ray each is on, and the kernel holds a single copy of the traversal.
+// Secondary rays wait on an explicit stack of weighted rays (DESIGN.md "Integrator").
+// ---------------------------------------------------------------------------------------
+struct PendingRay {
+  Ray ray;
+  float weight;
+  uint32_t remaining;
+  uint32_t path;
+};
+enum { JOB_SHADE = 0, JOB_SHADOW = 1, JOB_COLLECT = 2 };
+enum { ST_TRACE = 0, ST_NEXT_LIGHT, ST_LIGHTS_DONE, ST_SECONDARY, ST_NEXT_RAY, ST_DONE };
+
 // The n1/n2 walk of Computations::prepare (intersections.rs:141-160) over the sorted,
 // de-duplicated list of every intersection up to the hit.
-template <bool COUNT>
-__device__ inline void refractive_indices(const Scene& sc, const Ray& ray, const Hit& hit, float& n1, float& n2,
-                                          Counters& cn) {
-  float ts[RT_XS_CAP];
-  uint32_t ss[RT_XS_CAP];
-  CollectSink sink;
-  sink.ts = ts;
-  sink.ss = ss;
-  sink.n = 0;
-  sink.overflow = 0;
-  sink.tlimit = hit.t;
-  world_intersect<COUNT>(sc, ray, sink, cn);
-  cn.overflow += sink.overflow;
-  sort_entries(ts, ss, 0, sink.n);
-  int n = dedup_sorted(sc, ts, ss, 0, sink.n);
+__device__ inline void refractive_indices(const Scene& sc, float* ts, uint32_t* ss, int count, float hit_t,
+                                          int hit_shape, float& n1, float& n2) {
+  sort_entries(ts, ss, 0, count);
+  int n = dedup_sorted(sc, ts, ss, 0, count);
   n1 = 1.f;
   n2 = 1.f;
   uint32_t containers[RT_XS_CAP];
   int nc = 0;
-  uint32_t hit_vc = sc.shapes[hit.shape].vclass;
+  uint32_t hit_vc = sc.shapes[hit_shape].vclass;
   for (int i = 0; i < n; i++) {
     uint32_t s = ss[i];
     uint32_t vc = sc.shapes[s].vclass;
     // `x == &intersection`: same t, equal shape value (u,v are functions of ray and shape value)
-    bool is_hit = of_eq(ts[i], hit.t) && vclass_eq(vc, hit_vc);
+    bool is_hit = of_eq(ts[i], hit_t) && vclass_eq(vc, hit_vc);
     if (is_hit && nc > 0) n1 = sc.materials[sc.shapes[containers[nc - 1]].material].refractive_index;
     int pos = -1;
     for (int k = 0; k < nc; k++)
@@ -984,168 +1029,247 @@ __device__ inline void refractive_indices(const Scene& sc, const Ray& ray, const
   }
 }
 
-// World::color_at (world.rs:91-99) with the recursion of reflected_color / refracted_color
-// (world.rs:113-148) unrolled into an explicit stack of weighted rays (DESIGN.md "Integrator").
-struct PendingRay {
-  Ray ray;
-  float weight;
-  uint32_t remaining;
-  uint32_t path;
-};
-
 template <bool COUNT>
 __device__ inline V3 color_at(const Scene& sc, const RenderParams& rp, Ray primary, uint32_t remaining0,
                               uint32_t pixel, Counters& cn, Hit* primary_hit) {
   PendingRay stack[RT_MAX_RAY_STACK];
+  float xs_t[RT_XS_CAP];
+  uint32_t xs_s[RT_XS_CAP];
   int sp = 0;
-  stack[sp++] = PendingRay{primary, 1.f, remaining0, 1u};
   V3 result = v3(0.f, 0.f, 0.f);
   bool first = true;
   const float nl = (float)sc.n_lights;
-  while (sp > 0) {
-    PendingRay pr = stack[--sp];
-    const Ray ray = pr.ray;
-    Hit hit = trace_closest<COUNT>(sc, ray, cn);
-    if (first) {
-      if (primary_hit) *primary_hit = hit;
-      first = false;
-    }
-    if (hit.shape < 0) continue;
-    if (COUNT) cn.shaded++;
-    // ---- Computations::prepare (intersections.rs:121-139) ----
-    const uint4* raw = reinterpret_cast<const uint4*>(sc.shapes + hit.shape);
-    uint4 w0 = raw[0], w1 = raw[1];
-    uint32_t kf = w0.x, sxf = w0.y, mat_id = w0.z, prim = w1.y;
-    int parent = (int)w0.w;
-    float smn = __uint_as_float(w1.z), smx = __uint_as_float(w1.w);
-    if ((kf & RT_SHAPE_KIND_MASK) == RT_SMOOTH_TRIANGLE && hit.u != hit.u) {
-      // hit came through a csg list, which does not carry (u,v): recompute them (same arithmetic)
-      Ray local = ray;
-      V3 p1, e1, e2;
-      load_tri(sc, prim, p1, e1, e2);
-      if (sxf) local = xf_ray(sc, sxf, ray);
-      float tt;
-      isect_triangle(local, p1, e1, e2, tt, hit.u, hit.v);
-    }
-    V3 point = ray.o + hit.t * ray.d;
-    V3 eyev = -ray.d;
-    V3 lp = world_to_object(sc, sxf, parent, point);
-    V3 ln = local_normal_at(sc, kf, smn, smx, prim, lp, hit.u, hit.v);
-    V3 normalv = normal_to_world(sc, sxf, parent, ln);
-    if (dot(normalv, eyev) < 0.f) normalv = -normalv;
-    V3 reflectv = reflect(ray.d, normalv);
-    V3 over_point = point + 1e-4f * normalv;
-    V3 under_point = point - 1e-4f * normalv;
 
-    const RtMaterial& m = sc.materials[mat_id];
-    const float m_ambient = m.ambient, m_diffuse = m.diffuse, m_specular = m.specular, m_shininess = m.shininess;
-    const float m_reflective = m.reflective, m_transparency = m.transparency;
-    V3 mcolor;
-    if (m.pattern >= 0) {  // pattern_at_shape at over_point (patterns.rs:79-91, world.rs:72)
-      const RtPattern& pat = sc.patterns[m.pattern];
-      V3 op = world_to_object(sc, sxf, parent, over_point);
-      V3 pp = xf_point(sc.xforms[pat.xform].m, op);
-      mcolor = pattern_at(sc, pat, pp);
-    } else {
-      mcolor = v3(m.color[0], m.color[1], m.color[2]);
-    }
+  // the ray being shaded (JOB_SHADE) and what prepare() derived from its hit
+  Ray sray = primary;
+  float weight = 1.f;
+  uint32_t remaining = remaining0, path = 1u;
+  Hit hit{0.f, 0.f, 0.f, -1};
+  V3 eyev = v3(0.f, 0.f, 0.f), normalv = eyev, reflectv = eyev, over_point = eyev, under_point = eyev, mcolor = eyev;
+  float m_ambient = 0.f, m_diffuse = 0.f, m_specular = 0.f, m_shininess = 0.f, m_reflective = 0.f, m_transparency = 0.f;
+  // light loop
+  uint32_t li = 0, sample = 0;
+  float total = 0.f, distance = 0.f;
+  V3 surface_sum = v3(0.f, 0.f, 0.f);
+  float n1 = 1.f, n2 = 1.f;
 
-    // ---- World::shade_hit (world.rs:64-89): direct lighting, summed over lights ----
-    V3 surface_sum = v3(0.f, 0.f, 0.f);
-    for (uint32_t li = 0; li < sc.n_lights; li++) {
+  // the ray to trace next
+  Ray tray = primary;
+  int job = JOB_SHADE;
+  int st = ST_TRACE;
+  while (st != ST_DONE) {
+    // ---------------- the one traversal ----------------
+    Sink sink;
+    if (job == JOB_COLLECT)
+      sink.init_collect(xs_t, xs_s, hit.t);
+    else
+      sink.init_closest();
+    world_intersect<COUNT>(sc, tray, sink, cn);
+
+    // ---------------- what the traced ray was for ----------------
+    if (job == JOB_SHADE) {
+      hit = Hit{sink.t, sink.u, sink.v, sink.shape};
+      if (first) {
+        if (primary_hit) *primary_hit = hit;
+        first = false;
+      }
+      if (hit.shape < 0) {
+        st = ST_NEXT_RAY;
+      } else {
+        if (COUNT) cn.shaded++;
+        // ---- Computations::prepare (intersections.rs:121-139) ----
+        const uint4* raw = reinterpret_cast<const uint4*>(sc.shapes + hit.shape);
+        uint4 w0 = raw[0], w1 = raw[1];
+        uint32_t kf = w0.x, sxf = w0.y, mat_id = w0.z, prim = w1.y;
+        int parent = (int)w0.w;
+        float smn = __uint_as_float(w1.z), smx = __uint_as_float(w1.w);
+        if ((kf & RT_SHAPE_KIND_MASK) == RT_SMOOTH_TRIANGLE && hit.u != hit.u) {
+          // hit came through a csg list, which does not carry (u,v): recompute them (same arithmetic)
+          Ray local = sray;
+          V3 p1, e1, e2;
+          load_tri(sc, prim, p1, e1, e2);
+          if (sxf) local = xf_ray(sc, sxf, sray);
+          float tt;
+          isect_triangle(local, p1, e1, e2, tt, hit.u, hit.v);
+        }
+        V3 point = sray.o + hit.t * sray.d;
+        eyev = -sray.d;
+        V3 lp = world_to_object(sc, sxf, parent, point);
+        V3 ln = local_normal_at(sc, kf, smn, smx, prim, lp, hit.u, hit.v);
+        normalv = normal_to_world(sc, sxf, parent, ln);
+        if (dot(normalv, eyev) < 0.f) normalv = -normalv;
+        reflectv = reflect(sray.d, normalv);
+        over_point = point + 1e-4f * normalv;
+        under_point = point - 1e-4f * normalv;
+        const RtMaterial& m = sc.materials[mat_id];
+        m_ambient = m.ambient, m_diffuse = m.diffuse, m_specular = m.specular, m_shininess = m.shininess;
+        m_reflective = m.reflective, m_transparency = m.transparency;
+        if (m.pattern >= 0) {  // pattern_at_shape at over_point (patterns.rs:79-91, world.rs:72)
+          const RtPattern& pat = sc.patterns[m.pattern];
+          V3 op = world_to_object(sc, sxf, parent, over_point);
+          V3 pp = xf_point(sc.xforms[pat.xform].m, op);
+          mcolor = pattern_at(sc, pat, pp);
+        } else {
+          mcolor = v3(m.color[0], m.color[1], m.color[2]);
+        }
+        // ---- World::shade_hit (world.rs:64-89): direct lighting, summed over lights ----
+        surface_sum = v3(0.f, 0.f, 0.f);
+        li = 0;
+        sample = 0;
+        total = 0.f;
+        st = ST_NEXT_LIGHT;
+      }
+    } else if (job == JOB_SHADOW) {
+      // World::is_shadowed (world.rs:101-111): closest-hit semantics
+      bool shadowed = sink.shape >= 0 && sink.t < distance && (sc.shapes[sink.shape].kind_flags & RT_SHAPE_SHADOW);
       const RtLight& L = sc.lights[li];
       V3 lcol = v3(L.intensity[0], L.intensity[1], L.intensity[2]);
       V3 effective = mulc(mcolor, lcol);
       V3 ambient = m_ambient * effective;
-      V3 surface;
       if (L.kind == RT_LIGHT_POINT) {
         V3 lpos = v3(L.position[0], L.position[1], L.position[2]);
-        float intensity = is_shadowed<COUNT>(sc, lpos, over_point, cn) ? 0.f : 1.f;  // lights.rs:50-56
+        float intensity = shadowed ? 0.f : 1.f;  // lights.rs:50-56
         V3 diffuse = v3(0.f, 0.f, 0.f), specular = v3(0.f, 0.f, 0.f);
         phong_sample(lpos, over_point, eyev, normalv, effective, lcol, m_diffuse, m_specular, m_shininess, diffuse,
                      specular);
-        surface = ambient + intensity * (diffuse + specular);  // materials.rs:134
+        surface_sum = surface_sum + (ambient + intensity * (diffuse + specular));  // materials.rs:134
+        li++;
+        st = ST_NEXT_LIGHT;
       } else {
-        // AreaLight::intensity_at (lights.rs:123-134)
-        float total = 0.f;
-        for (uint32_t u = 0; u < L.usteps; u++)
-          for (uint32_t v = 0; v < L.vsteps; v++) {
-            V3 lpos = point_on_light(L, li, u, v, 0u, rp, pixel, pr.path);
-            if (!is_shadowed<COUNT>(sc, lpos, over_point, cn)) total += 1.f;
-          }
-        float nb = (float)(L.usteps * L.vsteps);
-        float intensity = total / nb;
-        // materials.rs:136-175
-        V3 sum = v3(0.f, 0.f, 0.f);
-        for (uint32_t u = 0; u < L.usteps; u++)
-          for (uint32_t v = 0; v < L.vsteps; v++) {
-            V3 lpos = point_on_light(L, li, u, v, 1u, rp, pixel, pr.path);
-            V3 diffuse, specular;
-            if (phong_sample(lpos, over_point, eyev, normalv, effective, lcol, m_diffuse, m_specular, m_shininess,
-                             diffuse, specular))
-              sum = (sum + diffuse) + specular;
-          }
-        sum = (1.f / nb) * sum;
-        surface = ambient + intensity * sum;
-      }
-      surface_sum = surface_sum + surface;
-    }
-    result = result + pr.weight * surface_sum;
-
-    // ---- secondary rays (world.rs:78-86, :113-148); once per light in the reference (Q4) ----
-    if (pr.remaining == 0 || sc.n_lights == 0) continue;
-    bool want_reflect = m_reflective != 0.f;
-    bool want_refract = m_transparency != 0.f;
-    if (!want_reflect && !want_refract) continue;
-    float reflectance = 1.f, transmittance = 1.f;
-    float n1 = 1.f, n2 = 1.f;
-    if (want_refract) refractive_indices<COUNT>(sc, ray, hit, n1, n2, cn);
-    if (m_reflective > 0.f && m_transparency > 0.f) {  // Computations::schlick (intersections.rs:177-192)
-      float cosv = dot(eyev, normalv);
-      bool tir = false;
-      if (n1 > n2) {
-        float n = n1 / n2;
-        float sin2_t = (n * n) * (1.f - cosv * cosv);
-        if (sin2_t > 1.f)
-          tir = true;
-        else
-          cosv = __builtin_sqrtf(1.f - sin2_t);
-      }
-      if (tir) {
-        reflectance = 1.f;
-      } else {
-        float r = (n1 - n2) / (n1 + n2);
-        float r0 = r * r;
-        float x = 1.f - cosv;
-        float x2 = x * x;
-        float x4 = x2 * x2;
-        reflectance = r0 + (1.f - r0) * (x * x4);
-      }
-      transmittance = 1.f - reflectance;
-    }
-    if (want_refract) {  // refracted_color (world.rs:127-148); pushed first so reflection is traced first
-      float n_ratio = n1 / n2;
-      float cos_i = dot(eyev, normalv);
-      float sin2_t = (n_ratio * n_ratio) * (1.f - cos_i * cos_i);
-      if (!(sin2_t > 1.f)) {
-        float cos_t = __builtin_sqrtf(1.f - sin2_t);
-        V3 direction = (n_ratio * cos_i - cos_t) * normalv - n_ratio * eyev;
-        float w = pr.weight * nl * m_transparency * transmittance;
-        if (sp < RT_MAX_RAY_STACK) {
-          stack[sp++] = PendingRay{Ray{under_point, direction}, w, pr.remaining - 1u, pr.path * 2u + 1u};
-          cn.refract++;
+        // AreaLight::intensity_at (lights.rs:123-134), one sample per traced ray
+        if (!shadowed) total += 1.f;
+        sample++;
+        uint32_t nbs = L.usteps * L.vsteps;
+        if (sample < nbs) {
+          st = ST_NEXT_LIGHT;  // next sample of the same light
         } else {
-          cn.overflow++;
+          float nb = (float)nbs;
+          float intensity = total / nb;
+          // materials.rs:136-175
+          V3 sum = v3(0.f, 0.f, 0.f);
+          for (uint32_t u = 0; u < L.usteps; u++)
+            for (uint32_t v = 0; v < L.vsteps; v++) {
+              V3 lpos = point_on_light(L, li, u, v, 1u, rp, pixel, path);
+              V3 diffuse, specular;
+              if (phong_sample(lpos, over_point, eyev, normalv, effective, lcol, m_diffuse, m_specular, m_shininess,
+                               diffuse, specular))
+                sum = (sum + diffuse) + specular;
+            }
+          sum = (1.f / nb) * sum;
+          surface_sum = surface_sum + (ambient + intensity * sum);
+          li++;
+          sample = 0;
+          total = 0.f;
+          st = ST_NEXT_LIGHT;
         }
       }
+    } else {  // JOB_COLLECT
+      cn.overflow += sink.overflow;
+      refractive_indices(sc, xs_t, xs_s, sink.n, hit.t, hit.shape, n1, n2);
+      st = ST_SECONDARY;
     }
-    if (want_reflect) {  // reflected_color (world.rs:113-125)
-      float w = pr.weight * nl * m_reflective * reflectance;
-      if (sp < RT_MAX_RAY_STACK) {
-        stack[sp++] = PendingRay{Ray{over_point, reflectv}, w, pr.remaining - 1u, pr.path * 2u};
-        cn.reflect++;
-      } else {
-        cn.overflow++;
+
+    // ---------------- advance the shading state until a ray has to be traced ----------------
+    while (st != ST_TRACE && st != ST_DONE) {
+      if (st == ST_NEXT_LIGHT) {
+        if (li < sc.n_lights) {
+          const RtLight& L = sc.lights[li];
+          V3 lpos;
+          if (L.kind == RT_LIGHT_POINT) {
+            lpos = v3(L.position[0], L.position[1], L.position[2]);
+          } else {
+            uint32_t u = sample / L.vsteps, v = sample % L.vsteps;  // u outer, v inner (lights.rs:125-126)
+            lpos = point_on_light(L, li, u, v, 0u, rp, pixel, path);
+          }
+          V3 v = lpos - over_point;
+          distance = magnitude(v);
+          tray = Ray{over_point, v / distance};
+          cn.shadow++;
+          job = JOB_SHADOW;
+          st = ST_TRACE;
+        } else {
+          st = ST_LIGHTS_DONE;
+        }
+      } else if (st == ST_LIGHTS_DONE) {
+        result = result + weight * surface_sum;
+        // ---- secondary rays (world.rs:78-86, :113-148); once per light in the reference (Q4) ----
+        bool want_reflect = m_reflective != 0.f, want_refract = m_transparency != 0.f;
+        if (remaining == 0 || sc.n_lights == 0 || (!want_reflect && !want_refract)) {
+          st = ST_NEXT_RAY;
+        } else if (want_refract) {
+          tray = sray;
+          job = JOB_COLLECT;
+          st = ST_TRACE;
+        } else {
+          n1 = 1.f;
+          n2 = 1.f;
+          st = ST_SECONDARY;
+        }
+      } else if (st == ST_SECONDARY) {
+        bool want_reflect = m_reflective != 0.f, want_refract = m_transparency != 0.f;
+        float reflectance = 1.f, transmittance = 1.f;
+        if (m_reflective > 0.f && m_transparency > 0.f) {  // Computations::schlick (intersections.rs:177-192)
+          float cosv = dot(eyev, normalv);
+          bool tir = false;
+          if (n1 > n2) {
+            float n = n1 / n2;
+            float sin2_t = (n * n) * (1.f - cosv * cosv);
+            if (sin2_t > 1.f)
+              tir = true;
+            else
+              cosv = __builtin_sqrtf(1.f - sin2_t);
+          }
+          if (tir) {
+            reflectance = 1.f;
+          } else {
+            float r = (n1 - n2) / (n1 + n2);
+            float r0 = r * r;
+            float x = 1.f - cosv;
+            float x2 = x * x;
+            float x4 = x2 * x2;
+            reflectance = r0 + (1.f - r0) * (x * x4);
+          }
+          transmittance = 1.f - reflectance;
+        }
+        if (want_refract) {  // refracted_color (world.rs:127-148); pushed first so reflection is traced first
+          float n_ratio = n1 / n2;
+          float cos_i = dot(eyev, normalv);
+          float sin2_t = (n_ratio * n_ratio) * (1.f - cos_i * cos_i);
+          if (!(sin2_t > 1.f)) {
+            float cos_t = __builtin_sqrtf(1.f - sin2_t);
+            V3 direction = (n_ratio * cos_i - cos_t) * normalv - n_ratio * eyev;
+            float w = weight * nl * m_transparency * transmittance;
+            if (sp < RT_MAX_RAY_STACK) {
+              stack[sp++] = PendingRay{Ray{under_point, direction}, w, remaining - 1u, path * 2u + 1u};
+              cn.refract++;
+            } else {
+              cn.overflow++;
+            }
+          }
+        }
+        if (want_reflect) {  // reflected_color (world.rs:113-125)
+          float w = weight * nl * m_reflective * reflectance;
+          if (sp < RT_MAX_RAY_STACK) {
+            stack[sp++] = PendingRay{Ray{over_point, reflectv}, w, remaining - 1u, path * 2u};
+            cn.reflect++;
+          } else {
+            cn.overflow++;
+          }
+        }
+        st = ST_NEXT_RAY;
+      } else {  // ST_NEXT_RAY
+        if (sp > 0) {
+          PendingRay pr = stack[--sp];
+          sray = pr.ray;
+          weight = pr.weight;
+          remaining = pr.remaining;
+          path = pr.path;
+          tray = sray;
+          job = JOB_SHADE;
+          st = ST_TRACE;
+        } else {
+          st = ST_DONE;
+        }
       }
     }
   }

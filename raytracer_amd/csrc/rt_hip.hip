@@ -33,13 +33,14 @@ __device__ __forceinline__ void flush_counters(const Counters& cn, unsigned long
   uint32_t a = wave_sum(cn.primary), b = wave_sum(cn.shadow), c = wave_sum(cn.reflect), d = wave_sum(cn.refract),
            e = wave_sum(cn.overflow);
   uint32_t w0 = wave_sum(cn.node_visits), w1 = wave_sum(cn.tri_tests), w2 = wave_sum(cn.shape_tests),
-           w3 = wave_sum(cn.shaded), w4 = wave_sum(cn.xforms);
+           w3 = wave_sum(cn.shaded), w4 = wave_sum(cn.xforms), w5 = wave_sum(cn.aux_tests);
   if ((threadIdx.x & 63) == 0) {
     if (w0) atomicAdd(g + 5, (unsigned long long)w0);
     if (w1) atomicAdd(g + 6, (unsigned long long)w1);
     if (w2) atomicAdd(g + 7, (unsigned long long)w2);
     if (w3) atomicAdd(g + 8, (unsigned long long)w3);
     if (w4) atomicAdd(g + 9, (unsigned long long)w4);
+    if (w5) atomicAdd(g + 10, (unsigned long long)w5);
     if (a) atomicAdd(g + 0, (unsigned long long)a);
     if (b) atomicAdd(g + 1, (unsigned long long)b);
     if (c) atomicAdd(g + 2, (unsigned long long)c);
@@ -51,14 +52,20 @@ __device__ __forceinline__ void flush_counters(const Counters& cn, unsigned long
 // Camera::render (camera.rs:66-84): one lane per pixel, one wave per 8x8 pixel tile, four waves
 // per 16x16 block.  Rows are the interleaved scanline tiles of this part.
 template <bool COUNT>
-__global__ __launch_bounds__(256) void k_render(Scene sc, RtCamera cam, RenderParams rp, PartInfo part,
+__global__ __launch_bounds__(RT_BLOCK) void k_render(Scene sc, RtCamera cam, RenderParams rp, PartInfo part,
                                                 float* __restrict__ out, uint8_t* __restrict__ mask,
                                                 int32_t* __restrict__ oid, float* __restrict__ ht,
                                                 unsigned long long* counters) {
   const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+#if RT_BLOCK == 256
   const uint32_t px = blockIdx.x * 16u + (wave & 1u) * 8u + (lane & 7u);
   const uint32_t ly = blockIdx.y * 16u + (wave >> 1) * 8u + (lane >> 3);
-  Counters cn = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#else  // one wave per block
+  const uint32_t px = blockIdx.x * 8u + (lane & 7u);
+  const uint32_t ly = blockIdx.y * 8u + (lane >> 3);
+  (void)wave;
+#endif
+  Counters cn = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (px < cam.hsize && ly < part.rows) {
     const uint32_t py = (ly / part.tile_h) * (part.n_parts * part.tile_h) + part.part * part.tile_h + (ly % part.tile_h);
     // Camera::ray_for_pixel (camera.rs:45-64)
@@ -85,13 +92,13 @@ __global__ __launch_bounds__(256) void k_render(Scene sc, RtCamera cam, RenderPa
 
 // World::color_at for caller-supplied rays (world.rs:91-99).
 template <bool COUNT>
-__global__ __launch_bounds__(256) void k_color_at(Scene sc, RenderParams rp, const float* __restrict__ origins,
+__global__ __launch_bounds__(RT_BLOCK) void k_color_at(Scene sc, RenderParams rp, const float* __restrict__ origins,
                                                   const float* __restrict__ directions, uint32_t n,
                                                   uint32_t remaining, float* __restrict__ out,
                                                   float* __restrict__ hit_t, int32_t* __restrict__ hit_id,
                                                   float* __restrict__ hit_uv, unsigned long long* counters) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  Counters cn = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  Counters cn = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (i < n) {
     Ray r{v3(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]),
           v3(directions[3 * i], directions[3 * i + 1], directions[3 * i + 2])};
@@ -273,6 +280,7 @@ int read_stats(RtContext* ctx, hipStream_t stream, RtStats* stats, double total_
   stats->shape_tests = h[7];
   stats->shaded_hits = h[8];
   stats->node_xforms = h[9];
+  stats->aux_tests = h[10];
   stats->kernel_ms = ms;
   stats->total_ms = total_ms;
   return RT_OK;
@@ -341,7 +349,14 @@ int rt_scene_create(RtContext* ctx, const RtScene* s, RtDeviceScene** out) {
     // the device copy of a node carries its aux root in the slot of n_children (unused on the device)
     rtaccel::Result acc = rtaccel::build(s);
     std::vector<RtNode> nodes(s->nodes, s->nodes + s->n_nodes);
-    for (uint32_t i = 0; i < s->n_nodes; i++) nodes[i].n_children = acc.root_of[i];
+    for (uint32_t i = 0; i < s->n_nodes; i++) {
+      if (acc.root_of[i] != rtaccel::kNone) {
+        nodes[i].n_children = acc.root_of[i];
+        nodes[i].flags |= RT_NODE_AUX;
+      } else {
+        nodes[i].n_children = acc.gate_next[i];
+      }
+    }
     const rtaccel::Node* an = nullptr;
     const rtaccel::Tri* at = nullptr;
     UP(d.nodes, nodes.data(), nodes.size())
@@ -401,6 +416,7 @@ int rt_accel_build(const RtScene* s, RtAccelView* out) {
   out->nodes = r->nodes.data();
   out->tris = r->tris.data();
   out->root_of = r->root_of.data();
+  out->gate_next = r->gate_next.data();
   out->owner = r;
   return RT_OK;
 }
@@ -426,10 +442,11 @@ int rt_render_device(RtContext* ctx, const RtDeviceScene* ds, const RtCamera* ca
   RenderParams rp = make_params(opts);
   HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, RT_N_COUNTERS * sizeof(unsigned long long), stream));
   if (part.rows > 0) {
-    dim3 grid((cam->hsize + 15) / 16, (part.rows + 15) / 16);
+    const uint32_t tile = RT_BLOCK == 256 ? 16u : 8u;
+    dim3 grid((cam->hsize + tile - 1) / tile, (part.rows + tile - 1) / tile);
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
     auto kern = (sc.flags & RT_RENDER_COUNT_WORK) ? k_render<true> : k_render<false>;
-    hipLaunchKernelGGL(kern, grid, dim3(256), 0, stream, sc, *cam, rp, part, d_out_rgb,
+    hipLaunchKernelGGL(kern, grid, dim3(RT_BLOCK), 0, stream, sc, *cam, rp, part, d_out_rgb,
                        d_aux ? d_aux->hit_mask : nullptr, d_aux ? d_aux->object_id : nullptr,
                        d_aux ? d_aux->hit_t : nullptr, ctx->d_counters);
     HIP_TRY(ctx, hipGetLastError());
@@ -540,7 +557,7 @@ int rt_color_at(RtContext* ctx, const RtDeviceScene* ds, const RtRenderOptions* 
   sc.flags = opts ? opts->flags : 0;
   RenderParams rp = make_params(opts);
   TRY_CLEAN(hipEventRecord(ctx->ev0, ctx->stream));
-  hipLaunchKernelGGL(k_color_at<false>, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, sc, rp, d_o, d_d, n, remaining,
+  hipLaunchKernelGGL(k_color_at<false>, dim3((n + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, ctx->stream, sc, rp, d_o, d_d, n, remaining,
                      d_rgb, d_t, d_id, d_uv, ctx->d_counters);
   TRY_CLEAN(hipGetLastError());
   TRY_CLEAN(hipEventRecord(ctx->ev1, ctx->stream));
