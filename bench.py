@@ -140,14 +140,31 @@ def main():
                                    C.c_void_p(stream.cuda_stream), C.byref(st)), "rt_render_device(stats)")
         kms.append(st.kernel_ms)
     kernel_ms = float(np.mean(kms))
-    # algorithmic bytes of one launch (SURVEY.md §8d / DESIGN.md "Measurement")
-    alg_bytes = (cst.node_visits * 32 + cst.tri_tests * 36 + cst.shape_tests * 32 + cst.shaded_hits * 36
-                 + cst.node_xforms * 48 + rows * cam.hsize * 12)
+    # algorithmic bytes and flops of one launch (SURVEY.md §8d / DESIGN.md "Measurement"): per-unit figures
+    # times the units the instrumented launch counted
+    alg_bytes = (cst.node_visits * 32 + cst.aux_tests * 32 + cst.tri_tests * 36 + cst.shape_tests * 32
+                 + cst.shaded_hits * 36 + cst.node_xforms * 48 + rows * cam.hsize * 12)
+    alg_flops = (cst.node_visits * 12 + cst.node_xforms * 33 + cst.aux_tests * 18 + cst.tri_tests * 24
+                 + cst.shape_tests * 30 + cst.shaded_hits * 140 + cst.primary * 36)
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+    # HBM traffic per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE doubled: gfx950
+    # counts 64 B per 128-B request, MI355X_MICROARCH.md "HBM"); null when no pass matches this workload
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        with open(tpath) as f:
+            tj = json.load(f)
+        if tj.get("workload") == f"{args.workload}.yaml {cam.hsize}x{cam.vsize}" and tj.get("parts") == world:
+            traffic = int(2 * tj["fetch_kb"] * 1024 + tj["write_kb"] * 1024)
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "kernel": "k_render", "kernel_ms": round(kernel_ms, 3), "algorithmic_bytes": int(alg_bytes),
-                "counters": {"node_visits": cst.node_visits, "tri_tests": cst.tri_tests,
+                "note": "algorithmic bytes are served by L1/L2 (scene is cache resident); see traffic for HBM bytes",
+                "valu": {"achieved": round(alg_flops / (kernel_ms * 1e-3) / 1e12, 3), "unit": "TFLOP/s",
+                         "peak_fma_packed": 157.3, "peak_no_fma_scalar": 39.3,
+                         "frac_of_no_fma_peak": round(alg_flops / (kernel_ms * 1e-3) / 1e12 / 39.3, 5),
+                         "algorithmic_flops": int(alg_flops)},
+                "counters": {"node_visits": cst.node_visits, "aux_box_tests": cst.aux_tests, "tri_tests": cst.tri_tests,
                              "shape_tests": cst.shape_tests, "shaded_hits": cst.shaded_hits,
                              "node_xforms": cst.node_xforms}}
 

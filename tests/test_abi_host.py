@@ -123,23 +123,28 @@ def test_group_boxes_equal_the_oracle(obj_files):
 
 
 def test_aux_bvh_is_well_formed(obj_files):
+    """rt_accel.h: one BVH per maximal subtree of identity-transform triangle groups; every triangle of
+    the subtree sits in exactly one leaf with its shape index and owning group; boxes nest and hold
+    their triangles; gate chains only skip groups whose box test is implied by nesting."""
     scene, hw, fs = _flat("small_dragons")
     a = abi.scene_arrays(fs)
     acc = abi.accel_arrays(host.hip_lib(), fs)
-    nodes, roots = a["nodes"], acc["root_of"]
-    has = np.flatnonzero(roots != 0xFFFFFFFF)
-    eligible = np.flatnonzero(((nodes["flags"] & abi.RT_NODE_ALL_TRIS) != 0) & (nodes["n_shapes"] >= 12))
-    assert np.array_equal(has, eligible) and len(has) > 0
+    nodes, shapes, roots, gate = a["nodes"], a["shapes"], acc["root_of"], acc["gate_next"]
+    NONE = 0xFFFFFFFF
+    has = np.flatnonzero(roots != NONE)
+    assert len(has) == 6  # dragons.yaml: six dragon.obj instances, each one covered subtree
     an, at = acc["nodes"], acc["tris"]
-    assert len(at) == int(nodes["n_shapes"][has].sum())
-    for gi in has[:50]:
-        n, ft = int(nodes["n_shapes"][gi]), int(nodes["first_tri"][gi])
-        geom = a["tri_geom"][ft:ft + n]
-        seen = np.zeros(n, dtype=int)
-        hdr = an[roots[gi]]
+    covered = np.zeros(len(shapes), dtype=int)
+    for R in has:
+        R = int(R)
+        end = int(nodes["skip"][R])
+        sub = np.arange(R, end)
+        assert np.all(nodes["xform"][R + 1:end] == 0), "only the subtree root may carry a transform"
+        n_tris = int(nodes["n_shapes"][sub].sum())
+        hdr = an[roots[R]]
         radius = hdr["left"].view(np.float32)
-        stack = [(int(roots[gi]) + 1, 0, np.full(3, -np.inf), np.full(3, np.inf))]
-        depth_max = 0
+        stack = [(int(roots[R]) + 1, 0, np.full(3, -np.inf), np.full(3, np.inf))]
+        depth_max, seen = 0, 0
         while stack:
             idx, depth, lo, hi = stack.pop()
             depth_max = max(depth_max, depth)
@@ -153,20 +158,36 @@ def test_aux_bvh_is_well_formed(obj_files):
                     continue
                 assert 1 <= cnt <= 4
                 for t in at[ref:ref + cnt]:
-                    k = int(t["k"])
-                    seen[k] += 1
-                    g = geom[k]
+                    si, owner = int(t["shape"]), int(t["owner"])
+                    covered[si] += 1
+                    seen += 1
+                    assert R <= owner < end and shapes["parent"][si] == owner
+                    g = a["tri_geom"][shapes["prim"][si]]
                     assert np.array_equal(t["p1"], g["p1"]) and np.array_equal(t["e1"], g["e1"]) and \
                         np.array_equal(t["e2"], g["e2"])
                     for v in (g["p1"], g["p1"] + g["e1"], g["p1"] + g["e2"]):
                         assert np.all(v >= mn) and np.all(v <= mx), "leaf box does not hold its triangle"
                         assert np.linalg.norm(v - hdr["lmin"]) <= radius
-        assert np.all(seen == 1), "every own triangle of the group must sit in exactly one leaf"
-        assert depth_max <= 22
-        e1, e2 = geom["e1"].astype(np.float64), geom["e2"].astype(np.float64)
-        l1, l2, l3 = (np.linalg.norm(x, axis=1) for x in (e1, e2, e2 - e1))
-        assert hdr["lmax"][0] >= np.max(np.maximum(np.maximum(l1, l2), l3)) * (1 - 1e-6)
-        assert hdr["lmax"][1] >= np.max(l1 * l2) * (1 - 1e-6)
+        assert seen == n_tris and depth_max <= 22
+        # gate chains: walking gate_next from any group reaches the root through ancestors only, and every
+        # ancestor that is skipped contains the box below it
+        for g0 in sub[1::7]:
+            g, below = int(g0), int(g0)
+            required = set()
+            while gate[g] != NONE:
+                g = int(gate[g])
+                required.add(g)
+            p = int(nodes["parent"][below])
+            while p != R:
+                inside = np.all(nodes["bmin"][below] >= nodes["bmin"][p]) and np.all(nodes["bmax"][below] <= nodes["bmax"][p])
+                assert inside or p in required
+                below, p = p, int(nodes["parent"][p])
+    in_sub = np.zeros(len(shapes), dtype=bool)
+    for R in has:
+        for i in range(int(R), int(nodes["skip"][R])):
+            f, n = int(nodes["first_shape"][i]), int(nodes["n_shapes"][i])
+            in_sub[f:f + n] = True
+    assert np.array_equal(covered, in_sub.astype(int)), "every triangle of a covered subtree sits in exactly one leaf"
 
 
 def test_scene_without_triangle_groups_has_no_aux():
