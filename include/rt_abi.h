@@ -211,6 +211,7 @@ typedef struct {
 } RtRenderOptions;
 #define RT_RENDER_NO_PRUNE 0x1u   /* visit every node the reference visits (no distance pruning) */
 #define RT_RENDER_COUNT_WORK 0x2u /* instrumented kernel: also fill the work counters of RtStats (slower) */
+#define RT_RENDER_WORK_MAP 0x8u   /* with COUNT_WORK: RtAux.hit_t receives each pixel's traversal work (box + shape tests) */
 #define RT_RENDER_NO_ACCEL 0x4u   /* test every own triangle of a group linearly, as the reference does
                                      (groups.rs:118-120), instead of through the library's auxiliary BVHs */
 

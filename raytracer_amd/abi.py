@@ -12,7 +12,7 @@ RT_VCLASS_NEVER = 0xFFFFFFFF
 RT_NODE_ALL_TRIS, RT_NODE_PRUNABLE = 1, 2
 RT_CSG_LEFT_IS_SHAPE, RT_CSG_RIGHT_IS_SHAPE = 1, 2
 RT_JITTER_CONST, RT_JITTER_COUNTER = 0, 1
-RT_RENDER_NO_PRUNE, RT_RENDER_COUNT_WORK, RT_RENDER_NO_ACCEL = 1, 2, 4
+RT_RENDER_NO_PRUNE, RT_RENDER_COUNT_WORK, RT_RENDER_NO_ACCEL, RT_RENDER_WORK_MAP = 1, 2, 4, 8
 
 # numpy dtypes of the device records (must match the C structs byte for byte)
 XFORM = np.dtype([("m", "<f4", 12)])
@@ -91,7 +91,7 @@ class RtAccelView(C.Structure):
 AUX_NODE = np.dtype([("lmin", "<f4", 3), ("left", "<u4"), ("lmax", "<f4", 3), ("lcount", "<u4"),
                      ("rmin", "<f4", 3), ("right", "<u4"), ("rmax", "<f4", 3), ("rcount", "<u4")])
 AUX_TRI = np.dtype([("p1", "<f4", 3), ("shape", "<u4"), ("e1", "<f4", 3), ("owner", "<u4"), ("e2", "<f4", 3),
-                    ("pad", "<u4")])
+                    ("kind_flags", "<u4")])
 assert AUX_NODE.itemsize == 64 and AUX_TRI.itemsize == 48
 
 EXPORTS = ["rt_accel_build", "rt_accel_free", "rt_abi_version", "rt_context_create", "rt_context_destroy", "rt_last_error", "rt_scene_create",

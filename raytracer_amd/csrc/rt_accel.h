@@ -26,7 +26,7 @@
 //     {lmin.xyz, left}  {lmax.xyz, lcount}  {rmin.xyz, right}  {rmax.xyz, rcount}
 //     count == 0: child is the node aux[left]; count > 0: child is the leaf
 //     aux_tris[left .. left+count), 3 float4 per triangle:
-//       {p1.xyz, shape index} {e1.xyz, owning node index} {e2.xyz, 0}      (indices as uint bits)
+//       {p1.xyz, shape index} {e1.xyz, owning node index} {e2.xyz, shape kind_flags}   (as uint bits)
 #pragma once
 
 #include <algorithm>
@@ -64,7 +64,7 @@ struct Tri {
   float e1[3];
   uint32_t owner;
   float e2[3];
-  uint32_t pad;
+  uint32_t kind_flags;
 };
 static_assert(sizeof(Tri) == 48, "aux triangle is 48 B");
 
@@ -84,6 +84,7 @@ struct Item {
 
 struct TreeBuilder {
   const RtTriGeom* geom = nullptr;  // RtScene::tri_geom
+  const RtShape* shapes_ = nullptr;  // RtScene::shapes
   std::vector<Item> items;
   std::vector<Node> nodes;  // local; [0] header, [1] top
   std::vector<Tri> tris;
@@ -145,6 +146,7 @@ struct TreeBuilder {
         std::memcpy(t.e2, g.e2, 12);
         t.shape = items[i].shape;
         t.owner = items[i].owner;
+        t.kind_flags = shapes_[items[i].shape].kind_flags;
         tris.push_back(t);
       }
       return;
@@ -247,6 +249,7 @@ inline Result build(const RtScene* s) {
       uint32_t R = roots[j];
       TreeBuilder tb;
       tb.geom = s->tri_geom;
+      tb.shapes_ = s->shapes;
       bool ok = true;
       for (uint32_t i = R; ok && i < s->nodes[R].skip; i++) {
         const RtNode& n = s->nodes[i];

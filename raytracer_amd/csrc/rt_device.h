@@ -13,15 +13,23 @@
 
 #define RT_MAX_XF_DEPTH 6    // nested non-identity group transforms along one path
 #define RT_MAX_RAY_STACK 8   // pending secondary rays per pixel (recursion_limit + 1 needed)
+#ifndef RT_CSG_CAP
 #define RT_CSG_CAP 32        // per-ray intersection entries while evaluating one csg tree
+#endif
 #define RT_CSG_DEPTH 8       // csg tree depth
+#ifndef RT_XS_CAP
 #define RT_XS_CAP 96         // per-ray entries for the n1/n2 container walk
+#endif
 #define RT_AUX_STACK 24      // per-lane auxiliary-BVH stack entries, kept in LDS (rt_accel.h kMaxDepth + 2)
 #ifndef RT_BLOCK
 #define RT_BLOCK 256         // threads per block of every kernel that traces (LDS stack stride): 256 or 64
 #endif
 #define RT_AUX_NONE 0xFFFFFFFFu
 #define RT_NODE_AUX 0x4u      // device copy only: this node is the root of a subtree covered by an auxiliary BVH
+#define RT_NODE_HAS_NOSHADOW 0x8u  // device copy only: a shape with shadow() == false lives in this subtree
+#define RT_SCENE_HAS_NOSHADOW 0x1u // Scene::props: some shape has shadow() == false
+#define RT_SCENE_SHADOW_TWO_PASS 0x4u // Scene::props: shadow-less shapes exist AND auxiliary BVHs exist: find F first, then any occluder
+#define RT_SCENE_RI_ALL_ONE 0x2u   // Scene::props: every material has refractive_index == 1 (n1 = n2 = 1 always)
 
 namespace rtd {
 
@@ -58,6 +66,7 @@ struct Counters {
   uint32_t primary, shadow, reflect, refract, overflow;
   // work counters (only maintained by the COUNT instantiations; bench roofline)
   uint32_t node_visits, tri_tests, shape_tests, shaded, xforms, aux_tests;
+  uint32_t work_shadow, work_collect;  // COUNT only: tests spent in shadow rays / n1-n2 collect passes
 };
 
 struct Scene {
@@ -78,6 +87,7 @@ struct Scene {
   const float4* aux_tris;   // their leaf triangles: 3 float4 per triangle, p1.w = offset in the group
   uint32_t n_shapes, n_nodes, n_csg_roots, n_lights, n_loose, recursion_limit;
   uint32_t flags;  // RT_RENDER_*
+  uint32_t props;  // RT_SCENE_* (derived by rt_scene_create)
 };
 
 // Matrix<4,4> * Point / Vector (matrices.rs:68-80, :220-236): row sums left to right.
@@ -306,6 +316,7 @@ __device__ __forceinline__ void load_tri(const Scene& sc, uint32_t prim, V3& p1,
 //           Q1): minimise (t, insertion rank) over t > 0.  Traversal order is therefore free.
 //  collect: every intersection with t <= tlimit (total order), for the n1/n2 container walk.
 // ---------------------------------------------------------------------------------------
+enum { SINK_CLOSEST = 0, SINK_COLLECT = 1, SINK_CLOSEST_NOSHADOW = 2, SINK_ANY_SHADOW = 3 };
 struct Sink {
   float t, u, v;
   int shape;
@@ -313,9 +324,13 @@ struct Sink {
   uint32_t* ss;
   int n;
   int overflow;
-  float tlimit;
-  bool collect;
-  __device__ __forceinline__ void init_closest() {
+  float tlimit;   // collect: keep t <= tlimit; any-shadow: distance to the light
+  float tF;       // any-shadow: nearest hit on a shadow-less shape (inf if none) ...
+  int sF;         // ... and its shape
+  float tcap;     // closest: upper bound of interest (inf, or the distance to the light)
+  int mode;
+  bool found;     // any-shadow: an occluder has been found, the traversal may stop
+  __device__ __forceinline__ void init(int mode_) {
     t = __builtin_inff();
     u = v = 0.f;
     shape = -1;
@@ -324,22 +339,44 @@ struct Sink {
     n = 0;
     overflow = 0;
     tlimit = 0.f;
-    collect = false;
+    tF = __builtin_inff();
+    sF = -1;
+    tcap = __builtin_inff();
+    mode = mode_;
+    found = false;
   }
+  __device__ __forceinline__ void init_closest() { init(SINK_CLOSEST); }
   __device__ __forceinline__ void init_collect(float* ts_, uint32_t* ss_, float tlimit_) {
-    init_closest();
+    init(SINK_COLLECT);
     ts = ts_;
     ss = ss_;
     tlimit = tlimit_;
-    collect = true;
+  }
+  // World::is_shadowed (world.rs:101-111) looks at the closest hit h* only: shadowed <=> t* < distance and
+  // h*.shape.shadow().  With F = closest hit among shadow-less shapes, that is equivalent to: some hit x on a
+  // shadow-casting shape has 0 < t_x < distance and (t_x, rank_x) < (t_F, rank_F).  F is found first
+  // (SINK_CLOSEST_NOSHADOW, only where such shapes exist), then any x ends the search (SINK_ANY_SHADOW).
+  __device__ __forceinline__ void init_any_shadow(float distance, float tF_, int sF_) {
+    init(SINK_ANY_SHADOW);
+    tlimit = distance;
+    tF = tF_;
+    sF = sF_;
+  }
+  // does this traversal look at a shape with these flags at all?
+  __device__ __forceinline__ bool takes(uint32_t kind_flags) const {
+    if (mode == SINK_CLOSEST_NOSHADOW) return !(kind_flags & RT_SHAPE_SHADOW);
+    if (mode == SINK_ANY_SHADOW) return (kind_flags & RT_SHAPE_SHADOW) != 0;
+    return true;
   }
   __device__ __forceinline__ bool wants(float tt, uint32_t s) const {
-    if (collect) return !of_gt(tt, tlimit);
+    if (mode == SINK_COLLECT) return !of_gt(tt, tlimit);
+    if (mode == SINK_ANY_SHADOW)
+      return !found && tt > 0.f && tt < tlimit && (sF < 0 || tt < tF || (tt == tF && (int)s < sF));
     return tt > 0.f && (shape < 0 || tt < t || (tt == t && (int)s < shape));
   }
   __device__ __forceinline__ void add(float tt, uint32_t s, float uu, float vv) {
     if (!wants(tt, s)) return;
-    if (collect) {
+    if (mode == SINK_COLLECT) {
       if (n < RT_XS_CAP) {
         ts[n] = tt;
         ss[n] = s;
@@ -347,6 +384,8 @@ struct Sink {
       } else {
         overflow = 1;
       }
+    } else if (mode == SINK_ANY_SHADOW) {
+      found = true;
     } else {
       t = tt;
       shape = (int)s;
@@ -354,8 +393,14 @@ struct Sink {
       v = vv;
     }
   }
-  __device__ __forceinline__ float limit() const { return collect ? tlimit : (shape < 0 ? __builtin_inff() : t); }
-  __device__ __forceinline__ bool wants_negative() const { return collect; }
+  // nothing beyond this t can matter any more
+  __device__ __forceinline__ float limit() const {
+    if (mode == SINK_COLLECT) return tlimit;
+    if (mode == SINK_ANY_SHADOW) return found ? -__builtin_inff() : __builtin_fminf(tlimit, tF);
+    return shape < 0 ? tcap : __builtin_fminf(t, tcap);  // tcap: nothing at or beyond it can matter (shadow rays)
+  }
+  __device__ __forceinline__ bool wants_negative() const { return mode == SINK_COLLECT; }
+  __device__ __forceinline__ bool done() const { return mode == SINK_ANY_SHADOW && found; }
 };
 
 // Shape::intersect (shapes.rs:204-246): inverse-transform the ray, dispatch on kind.
@@ -364,6 +409,7 @@ __device__ __forceinline__ void shape_intersect(const Scene& sc, uint32_t si, co
   const uint4* raw = reinterpret_cast<const uint4*>(sc.shapes + si);
   uint4 w0 = raw[0], w1 = raw[1];
   uint32_t kf = w0.x, xform = w0.y, prim = w1.y;
+  if (!sink.takes(kf)) return;
   float mn = __uint_as_float(w1.z), mx = __uint_as_float(w1.w);
   Ray local = xform ? xf_ray(sc, xform, ray) : ray;
   float ts[4];
@@ -395,6 +441,7 @@ struct CsgList {
   uint32_t s[RT_CSG_CAP];
   int n;
   int overflow;
+  __device__ __forceinline__ bool takes(uint32_t) const { return true; }
   __device__ __forceinline__ void add(float tt, uint32_t ss, float, float) {
     if (n < RT_CSG_CAP) {
       t[n] = tt;
@@ -589,14 +636,15 @@ __device__ inline bool aux_intersect(const Scene& sc, uint32_t root_node, uint32
       for (uint32_t k = 0; k < cnt; k++) {
         float4 a = T[3 * k], b = T[3 * k + 1], c = T[3 * k + 2];
         float t, u, v;
-        if (isect_triangle(cur, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), v3(c.x, c.y, c.z), t, u, v)) {
+        if (sink.takes(__float_as_uint(c.w)) &&
+            isect_triangle(cur, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), v3(c.x, c.y, c.z), t, u, v)) {
           uint32_t shape = __float_as_uint(a.w);
           if (sink.wants(t, shape) && aux_gate<COUNT>(sc, __float_as_uint(b.w), root_node, cur, cn))
             sink.add(t, shape, u, v);
         }
       }
     }
-    if (sp == 0) break;
+    if (sp == 0 || sink.done()) break;
     ref = stk[(--sp) * RT_BLOCK];
   }
   return true;
@@ -640,7 +688,8 @@ __device__ inline void world_intersect(const Scene& sc, const Ray& ray, Sink& si
     L.overflow = 0;
     for (uint32_t c = 0; c < sc.n_csg_roots; c++) {
       csg_eval(sc, sc.csg_roots[c], ray, L);
-      for (int i = 0; i < L.n; i++) sink.add(L.t[i], L.s[i], __builtin_nanf(""), __builtin_nanf(""));
+      for (int i = 0; i < L.n; i++)
+        if (sink.takes(sc.shapes[L.s[i]].kind_flags)) sink.add(L.t[i], L.s[i], __builtin_nanf(""), __builtin_nanf(""));
     }
     cn.overflow += L.overflow;
   }
@@ -657,6 +706,10 @@ __device__ inline void world_intersect(const Scene& sc, const Ray& ray, Sink& si
       uint4 w0 = raw[0], w1 = raw[1], w2 = raw[2], w3 = raw[3];
       const uint32_t xform = w0.w, flags = w1.w, skip = w2.z;
       bool descend = false;
+      if (sink.done()) my_i = 0xFFFFFFFFu;  // an occluder is enough (any-shadow): this lane is finished
+      if (my_i == i && sink.mode == SINK_CLOSEST_NOSHADOW && !(flags & RT_NODE_HAS_NOSHADOW)) {
+        my_i = skip;  // nothing shadow-less below this group
+      }
       if (my_i == i) {
         if (i >= leave_at) {
           int par = (int)w2.w;
@@ -694,7 +747,8 @@ __device__ inline void world_intersect(const Scene& sc, const Ray& ray, Sink& si
             V3 p1, e1, e2;
             load_tri(sc, w3.x + k, p1, e1, e2);
             float t, u, v;
-            if (descend && isect_triangle(cur, p1, e1, e2, t, u, v)) sink.add(t, first_shape + k, u, v);
+            if (descend && sink.takes(sc.shapes[first_shape + k].kind_flags) && isect_triangle(cur, p1, e1, e2, t, u, v))
+              sink.add(t, first_shape + k, u, v);
           }
         } else {
           if (COUNT && descend) cn.shape_tests += n_shapes;
@@ -707,11 +761,13 @@ __device__ inline void world_intersect(const Scene& sc, const Ray& ray, Sink& si
         if (my_i == i) my_i = skip;
         i = skip;
       }
+      if (!wave_any(my_i != 0xFFFFFFFFu)) break;  // every lane of the wave is finished
     }
   }
   // loose shapes (world.rs:56-59): the last n_loose entries of shapes[]
   if (COUNT) cn.shape_tests += sc.n_loose;
-  for (uint32_t k = sc.n_shapes - sc.n_loose; k < sc.n_shapes; k++) shape_intersect(sc, k, ray, sink);
+  for (uint32_t k = sc.n_shapes - sc.n_loose; k < sc.n_shapes; k++)
+    if (!sink.done()) shape_intersect(sc, k, ray, sink);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -993,7 +1049,7 @@ struct PendingRay {
   uint32_t remaining;
   uint32_t path;
 };
-enum { JOB_SHADE = 0, JOB_SHADOW = 1, JOB_COLLECT = 2 };
+enum { JOB_SHADE = 0, JOB_SHADOW = 1, JOB_COLLECT = 2, JOB_SHADOW_F = 3 };
 enum { ST_TRACE = 0, ST_NEXT_LIGHT, ST_LIGHTS_DONE, ST_SECONDARY, ST_NEXT_RAY, ST_DONE };
 
 // The n1/n2 walk of Computations::prepare (intersections.rs:141-160) over the sorted,
@@ -1052,6 +1108,8 @@ __device__ inline V3 color_at(const Scene& sc, const RenderParams& rp, Ray prima
   float total = 0.f, distance = 0.f;
   V3 surface_sum = v3(0.f, 0.f, 0.f);
   float n1 = 1.f, n2 = 1.f;
+  float shadow_tF = __builtin_inff();
+  int shadow_sF = -1;
 
   // the ray to trace next
   Ray tray = primary;
@@ -1062,9 +1120,22 @@ __device__ inline V3 color_at(const Scene& sc, const RenderParams& rp, Ray prima
     Sink sink;
     if (job == JOB_COLLECT)
       sink.init_collect(xs_t, xs_s, hit.t);
+    else if (job == JOB_SHADOW && (sc.props & RT_SCENE_HAS_NOSHADOW) && !(sc.props & RT_SCENE_SHADOW_TWO_PASS)) {
+      sink.init_closest();  // small scene with shadow-less shapes: one closest-hit pass, capped at the light
+      sink.tcap = distance;
+    } else if (job == JOB_SHADOW)
+      sink.init_any_shadow(distance, shadow_tF, shadow_sF);
+    else if (job == JOB_SHADOW_F)
+      sink.init(SINK_CLOSEST_NOSHADOW);
     else
       sink.init_closest();
+    const uint32_t work0 = COUNT ? cn.node_visits + cn.aux_tests + cn.tri_tests + cn.shape_tests : 0u;
     world_intersect<COUNT>(sc, tray, sink, cn);
+    if (COUNT) {
+      uint32_t dw = cn.node_visits + cn.aux_tests + cn.tri_tests + cn.shape_tests - work0;
+      if (job == JOB_SHADOW || job == JOB_SHADOW_F) cn.work_shadow += dw;
+      if (job == JOB_COLLECT) cn.work_collect += dw;
+    }
 
     // ---------------- what the traced ray was for ----------------
     if (job == JOB_SHADE) {
@@ -1119,9 +1190,16 @@ __device__ inline V3 color_at(const Scene& sc, const RenderParams& rp, Ray prima
         total = 0.f;
         st = ST_NEXT_LIGHT;
       }
+    } else if (job == JOB_SHADOW_F) {
+      shadow_tF = sink.t;  // closest shadow-less hit (inf, -1 if none); now look for an occluder in front of it
+      shadow_sF = sink.shape;
+      job = JOB_SHADOW;
+      st = ST_TRACE;
     } else if (job == JOB_SHADOW) {
-      // World::is_shadowed (world.rs:101-111): closest-hit semantics
-      bool shadowed = sink.shape >= 0 && sink.t < distance && (sc.shapes[sink.shape].kind_flags & RT_SHAPE_SHADOW);
+      // World::is_shadowed (world.rs:101-111): closest-hit semantics, see Sink::init_any_shadow
+      bool shadowed = sink.mode == SINK_ANY_SHADOW
+                          ? sink.found
+                          : (sink.shape >= 0 && sink.t < distance && (sc.shapes[sink.shape].kind_flags & RT_SHAPE_SHADOW));
       const RtLight& L = sc.lights[li];
       V3 lcol = v3(L.intensity[0], L.intensity[1], L.intensity[2]);
       V3 effective = mulc(mcolor, lcol);
@@ -1185,7 +1263,9 @@ __device__ inline V3 color_at(const Scene& sc, const RenderParams& rp, Ray prima
           distance = magnitude(v);
           tray = Ray{over_point, v / distance};
           cn.shadow++;
-          job = JOB_SHADOW;
+          shadow_tF = __builtin_inff();
+          shadow_sF = -1;
+          job = (sc.props & RT_SCENE_SHADOW_TWO_PASS) ? JOB_SHADOW_F : JOB_SHADOW;
           st = ST_TRACE;
         } else {
           st = ST_LIGHTS_DONE;
@@ -1196,7 +1276,7 @@ __device__ inline V3 color_at(const Scene& sc, const RenderParams& rp, Ray prima
         bool want_reflect = m_reflective != 0.f, want_refract = m_transparency != 0.f;
         if (remaining == 0 || sc.n_lights == 0 || (!want_reflect && !want_refract)) {
           st = ST_NEXT_RAY;
-        } else if (want_refract) {
+        } else if (want_refract && !(sc.props & RT_SCENE_RI_ALL_ONE)) {
           tray = sray;
           job = JOB_COLLECT;
           st = ST_TRACE;

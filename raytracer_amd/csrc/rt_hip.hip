@@ -65,7 +65,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_render(Scene sc, RtCamera cam, Ren
   const uint32_t ly = blockIdx.y * 8u + (lane >> 3);
   (void)wave;
 #endif
-  Counters cn = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  Counters cn = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (px < cam.hsize && ly < part.rows) {
     const uint32_t py = (ly / part.tile_h) * (part.n_parts * part.tile_h) + part.part * part.tile_h + (ly % part.tile_h);
     // Camera::ray_for_pixel (camera.rs:45-64)
@@ -85,7 +85,14 @@ __global__ __launch_bounds__(RT_BLOCK) void k_render(Scene sc, RtCamera cam, Ren
     out[3 * idx + 2] = col.z;
     if (mask) mask[idx] = ph.shape >= 0 ? 1 : 0;
     if (oid) oid[idx] = ph.shape;
-    if (ht) ht[idx] = ph.shape >= 0 ? ph.t : __builtin_nanf("");
+    if (ht) {
+      if (COUNT && (sc.flags & RT_RENDER_WORK_MAP))  // diagnostics: this pixel's traversal work instead of hit t
+        ht[idx] = (sc.flags & 0x10u) ? (float)cn.work_shadow
+                  : (sc.flags & 0x20u) ? (float)cn.work_collect
+                                       : (float)(cn.node_visits + cn.aux_tests + cn.tri_tests + cn.shape_tests);
+      else
+        ht[idx] = ph.shape >= 0 ? ph.t : __builtin_nanf("");
+    }
   }
   flush_counters(cn, counters);
 }
@@ -98,7 +105,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_color_at(Scene sc, RenderParams rp
                                                   float* __restrict__ hit_t, int32_t* __restrict__ hit_id,
                                                   float* __restrict__ hit_uv, unsigned long long* counters) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  Counters cn = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  Counters cn = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (i < n) {
     Ray r{v3(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]),
           v3(directions[3 * i], directions[3 * i + 1], directions[3 * i + 2])};
@@ -349,6 +356,17 @@ int rt_scene_create(RtContext* ctx, const RtScene* s, RtDeviceScene** out) {
     // the device copy of a node carries its aux root in the slot of n_children (unused on the device)
     rtaccel::Result acc = rtaccel::build(s);
     std::vector<RtNode> nodes(s->nodes, s->nodes + s->n_nodes);
+    // groups that hold a shape with shadow() == false somewhere below them (any-shadow search, rt_device.h)
+    for (uint32_t i = 0; i < s->n_shapes; i++)
+      if (!(s->shapes[i].kind_flags & RT_SHAPE_SHADOW)) {
+        d.props |= RT_SCENE_HAS_NOSHADOW;
+        for (int32_t g = s->shapes[i].parent; g >= 0 && !(nodes[g].flags & RT_NODE_HAS_NOSHADOW); g = nodes[g].parent)
+          nodes[g].flags |= RT_NODE_HAS_NOSHADOW;
+      }
+    bool ri_one = true;
+    for (uint32_t i = 0; i < s->n_materials; i++) ri_one = ri_one && s->materials[i].refractive_index == 1.0f;
+    if (ri_one) d.props |= RT_SCENE_RI_ALL_ONE;
+    if ((d.props & RT_SCENE_HAS_NOSHADOW) && !acc.nodes.empty()) d.props |= RT_SCENE_SHADOW_TWO_PASS;
     for (uint32_t i = 0; i < s->n_nodes; i++) {
       if (acc.root_of[i] != rtaccel::kNone) {
         nodes[i].n_children = acc.root_of[i];

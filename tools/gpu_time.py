@@ -29,7 +29,7 @@ for spec in specs:
     ms, st = [], abi.RtStats()
     for _ in range(6):
         rc = lib.rt_render_device(ctx, ds, C.byref(rcam), C.byref(opts), out.data_ptr(), None, None, C.byref(st))
-        assert rc == 0, lib.rt_last_error(ctx).decode()
+        assert rc in (0, -5), lib.rt_last_error(ctx).decode()  # -5: list overflow (experiments with small caps)
         ms.append(st.kernel_ms)
     rays = st.primary + st.shadow + st.reflect + st.refract
     print(f"{label:>12} {spec:<24} min {min(ms):8.3f} ms  med {sorted(ms)[len(ms) // 2]:8.3f} ms  "
