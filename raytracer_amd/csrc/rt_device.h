@@ -1356,4 +1356,219 @@ __device__ inline V3 color_at(const Scene& sc, const RenderParams& rp, Ray prima
   return result;
 }
 
+// ---------------------------------------------------------------------------------------
+// Direct integrator for worlds without groups (every sample scene built from loose shapes and
+// CSG): World::intersect is a short loop, so the shadow / secondary traversals are simply inlined
+// where shade_hit needs them (world.rs:64-148) instead of going through the job loop above.
+// Same arithmetic, same accumulation order: the two integrators produce the same bits.
+// ---------------------------------------------------------------------------------------
+template <bool COUNT>
+__device__ __forceinline__ void simple_intersect(const Scene& sc, const Ray& ray, Sink& sink, Counters& cn) {
+  if (sc.n_csg_roots) {  // world.rs:45-49
+    CsgList L;
+    L.overflow = 0;
+    for (uint32_t c = 0; c < sc.n_csg_roots; c++) {
+      csg_eval(sc, sc.csg_roots[c], ray, L);
+      for (int i = 0; i < L.n; i++)
+        if (sink.takes(sc.shapes[L.s[i]].kind_flags)) sink.add(L.t[i], L.s[i], __builtin_nanf(""), __builtin_nanf(""));
+    }
+    cn.overflow += L.overflow;
+  }
+  if (COUNT) cn.shape_tests += sc.n_loose;
+  for (uint32_t k = sc.n_shapes - sc.n_loose; k < sc.n_shapes; k++)  // world.rs:56-59
+    if (!sink.done()) shape_intersect(sc, k, ray, sink);
+}
+template <bool COUNT>
+__device__ __forceinline__ Hit direct_closest(const Scene& sc, const Ray& ray, Counters& cn) {
+  Sink sink;
+  sink.init_closest();
+  simple_intersect<COUNT>(sc, ray, sink, cn);
+  return Hit{sink.t, sink.u, sink.v, sink.shape};
+}
+// World::is_shadowed (world.rs:101-111), see Sink::init_any_shadow for the two equivalent searches
+template <bool COUNT>
+__device__ __forceinline__ bool direct_is_shadowed(const Scene& sc, V3 light_position, V3 p, Counters& cn) {
+  V3 v = light_position - p;
+  float distance = magnitude(v);
+  V3 direction = v / distance;
+  cn.shadow++;
+  Sink sink;
+  if (sc.props & RT_SCENE_HAS_NOSHADOW) {
+    sink.init_closest();
+    sink.tcap = distance;
+    simple_intersect<COUNT>(sc, Ray{p, direction}, sink, cn);
+    return sink.shape >= 0 && sink.t < distance && (sc.shapes[sink.shape].kind_flags & RT_SHAPE_SHADOW);
+  }
+  sink.init_any_shadow(distance, __builtin_inff(), -1);
+  simple_intersect<COUNT>(sc, Ray{p, direction}, sink, cn);
+  return sink.found;
+}
+
+template <bool COUNT>
+__device__ inline V3 color_at_direct(const Scene& sc, const RenderParams& rp, Ray primary, uint32_t remaining0,
+                              uint32_t pixel, Counters& cn, Hit* primary_hit) {
+  PendingRay stack[RT_MAX_RAY_STACK];
+  int sp = 0;
+  stack[sp++] = PendingRay{primary, 1.f, remaining0, 1u};
+  V3 result = v3(0.f, 0.f, 0.f);
+  bool first = true;
+  const float nl = (float)sc.n_lights;
+  while (sp > 0) {
+    PendingRay pr = stack[--sp];
+    const Ray ray = pr.ray;
+    Hit hit = direct_closest<COUNT>(sc, ray, cn);
+    if (first) {
+      if (primary_hit) *primary_hit = hit;
+      first = false;
+    }
+    if (hit.shape < 0) continue;
+    if (COUNT) cn.shaded++;
+    // ---- Computations::prepare (intersections.rs:121-139) ----
+    const uint4* raw = reinterpret_cast<const uint4*>(sc.shapes + hit.shape);
+    uint4 w0 = raw[0], w1 = raw[1];
+    uint32_t kf = w0.x, sxf = w0.y, mat_id = w0.z, prim = w1.y;
+    int parent = (int)w0.w;
+    float smn = __uint_as_float(w1.z), smx = __uint_as_float(w1.w);
+    if ((kf & RT_SHAPE_KIND_MASK) == RT_SMOOTH_TRIANGLE && hit.u != hit.u) {
+      // hit came through a csg list, which does not carry (u,v): recompute them (same arithmetic)
+      Ray local = ray;
+      V3 p1, e1, e2;
+      load_tri(sc, prim, p1, e1, e2);
+      if (sxf) local = xf_ray(sc, sxf, ray);
+      float tt;
+      isect_triangle(local, p1, e1, e2, tt, hit.u, hit.v);
+    }
+    V3 point = ray.o + hit.t * ray.d;
+    V3 eyev = -ray.d;
+    V3 lp = world_to_object(sc, sxf, parent, point);
+    V3 ln = local_normal_at(sc, kf, smn, smx, prim, lp, hit.u, hit.v);
+    V3 normalv = normal_to_world(sc, sxf, parent, ln);
+    if (dot(normalv, eyev) < 0.f) normalv = -normalv;
+    V3 reflectv = reflect(ray.d, normalv);
+    V3 over_point = point + 1e-4f * normalv;
+    V3 under_point = point - 1e-4f * normalv;
+
+    const RtMaterial& m = sc.materials[mat_id];
+    const float m_ambient = m.ambient, m_diffuse = m.diffuse, m_specular = m.specular, m_shininess = m.shininess;
+    const float m_reflective = m.reflective, m_transparency = m.transparency;
+    V3 mcolor;
+    if (m.pattern >= 0) {  // pattern_at_shape at over_point (patterns.rs:79-91, world.rs:72)
+      const RtPattern& pat = sc.patterns[m.pattern];
+      V3 op = world_to_object(sc, sxf, parent, over_point);
+      V3 pp = xf_point(sc.xforms[pat.xform].m, op);
+      mcolor = pattern_at(sc, pat, pp);
+    } else {
+      mcolor = v3(m.color[0], m.color[1], m.color[2]);
+    }
+
+    // ---- World::shade_hit (world.rs:64-89): direct lighting, summed over lights ----
+    V3 surface_sum = v3(0.f, 0.f, 0.f);
+    for (uint32_t li = 0; li < sc.n_lights; li++) {
+      const RtLight& L = sc.lights[li];
+      V3 lcol = v3(L.intensity[0], L.intensity[1], L.intensity[2]);
+      V3 effective = mulc(mcolor, lcol);
+      V3 ambient = m_ambient * effective;
+      V3 surface;
+      if (L.kind == RT_LIGHT_POINT) {
+        V3 lpos = v3(L.position[0], L.position[1], L.position[2]);
+        float intensity = direct_is_shadowed<COUNT>(sc, lpos, over_point, cn) ? 0.f : 1.f;  // lights.rs:50-56
+        V3 diffuse = v3(0.f, 0.f, 0.f), specular = v3(0.f, 0.f, 0.f);
+        phong_sample(lpos, over_point, eyev, normalv, effective, lcol, m_diffuse, m_specular, m_shininess, diffuse,
+                     specular);
+        surface = ambient + intensity * (diffuse + specular);  // materials.rs:134
+      } else {
+        // AreaLight::intensity_at (lights.rs:123-134)
+        float total = 0.f;
+        for (uint32_t u = 0; u < L.usteps; u++)
+          for (uint32_t v = 0; v < L.vsteps; v++) {
+            V3 lpos = point_on_light(L, li, u, v, 0u, rp, pixel, pr.path);
+            if (!direct_is_shadowed<COUNT>(sc, lpos, over_point, cn)) total += 1.f;
+          }
+        float nb = (float)(L.usteps * L.vsteps);
+        float intensity = total / nb;
+        // materials.rs:136-175
+        V3 sum = v3(0.f, 0.f, 0.f);
+        for (uint32_t u = 0; u < L.usteps; u++)
+          for (uint32_t v = 0; v < L.vsteps; v++) {
+            V3 lpos = point_on_light(L, li, u, v, 1u, rp, pixel, pr.path);
+            V3 diffuse, specular;
+            if (phong_sample(lpos, over_point, eyev, normalv, effective, lcol, m_diffuse, m_specular, m_shininess,
+                             diffuse, specular))
+              sum = (sum + diffuse) + specular;
+          }
+        sum = (1.f / nb) * sum;
+        surface = ambient + intensity * sum;
+      }
+      surface_sum = surface_sum + surface;
+    }
+    result = result + pr.weight * surface_sum;
+
+    // ---- secondary rays (world.rs:78-86, :113-148); once per light in the reference (Q4) ----
+    if (pr.remaining == 0 || sc.n_lights == 0) continue;
+    bool want_reflect = m_reflective != 0.f;
+    bool want_refract = m_transparency != 0.f;
+    if (!want_reflect && !want_refract) continue;
+    float reflectance = 1.f, transmittance = 1.f;
+    float n1 = 1.f, n2 = 1.f;
+    if (want_refract && !(sc.props & RT_SCENE_RI_ALL_ONE)) {
+      float xs_t[RT_XS_CAP];
+      uint32_t xs_s[RT_XS_CAP];
+      Sink cs;
+      cs.init_collect(xs_t, xs_s, hit.t);
+      simple_intersect<COUNT>(sc, ray, cs, cn);
+      cn.overflow += cs.overflow;
+      refractive_indices(sc, xs_t, xs_s, cs.n, hit.t, hit.shape, n1, n2);
+    }
+    if (m_reflective > 0.f && m_transparency > 0.f) {  // Computations::schlick (intersections.rs:177-192)
+      float cosv = dot(eyev, normalv);
+      bool tir = false;
+      if (n1 > n2) {
+        float n = n1 / n2;
+        float sin2_t = (n * n) * (1.f - cosv * cosv);
+        if (sin2_t > 1.f)
+          tir = true;
+        else
+          cosv = __builtin_sqrtf(1.f - sin2_t);
+      }
+      if (tir) {
+        reflectance = 1.f;
+      } else {
+        float r = (n1 - n2) / (n1 + n2);
+        float r0 = r * r;
+        float x = 1.f - cosv;
+        float x2 = x * x;
+        float x4 = x2 * x2;
+        reflectance = r0 + (1.f - r0) * (x * x4);
+      }
+      transmittance = 1.f - reflectance;
+    }
+    if (want_refract) {  // refracted_color (world.rs:127-148); pushed first so reflection is traced first
+      float n_ratio = n1 / n2;
+      float cos_i = dot(eyev, normalv);
+      float sin2_t = (n_ratio * n_ratio) * (1.f - cos_i * cos_i);
+      if (!(sin2_t > 1.f)) {
+        float cos_t = __builtin_sqrtf(1.f - sin2_t);
+        V3 direction = (n_ratio * cos_i - cos_t) * normalv - n_ratio * eyev;
+        float w = pr.weight * nl * m_transparency * transmittance;
+        if (sp < RT_MAX_RAY_STACK) {
+          stack[sp++] = PendingRay{Ray{under_point, direction}, w, pr.remaining - 1u, pr.path * 2u + 1u};
+          cn.refract++;
+        } else {
+          cn.overflow++;
+        }
+      }
+    }
+    if (want_reflect) {  // reflected_color (world.rs:113-125)
+      float w = pr.weight * nl * m_reflective * reflectance;
+      if (sp < RT_MAX_RAY_STACK) {
+        stack[sp++] = PendingRay{Ray{over_point, reflectv}, w, pr.remaining - 1u, pr.path * 2u};
+        cn.reflect++;
+      } else {
+        cn.overflow++;
+      }
+    }
+  }
+  return result;
+}
+
 }  // namespace rtd

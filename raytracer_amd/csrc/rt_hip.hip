@@ -51,7 +51,7 @@ __device__ __forceinline__ void flush_counters(const Counters& cn, unsigned long
 
 // Camera::render (camera.rs:66-84): one lane per pixel, one wave per 8x8 pixel tile, four waves
 // per 16x16 block.  Rows are the interleaved scanline tiles of this part.
-template <bool COUNT>
+template <bool COUNT, bool SIMPLE>
 __global__ __launch_bounds__(RT_BLOCK) void k_render(Scene sc, RtCamera cam, RenderParams rp, PartInfo part,
                                                 float* __restrict__ out, uint8_t* __restrict__ mask,
                                                 int32_t* __restrict__ oid, float* __restrict__ ht,
@@ -78,7 +78,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_render(Scene sc, RtCamera cam, Ren
     V3 direction = normalize(pixel - origin);
     cn.primary = 1;
     Hit ph;
-    V3 col = color_at<COUNT>(sc, rp, Ray{origin, direction}, sc.recursion_limit, py * cam.hsize + px, cn, &ph);
+    V3 col = SIMPLE ? color_at_direct<COUNT>(sc, rp, Ray{origin, direction}, sc.recursion_limit, py * cam.hsize + px, cn, &ph)
+                    : color_at<COUNT>(sc, rp, Ray{origin, direction}, sc.recursion_limit, py * cam.hsize + px, cn, &ph);
     size_t idx = (size_t)ly * cam.hsize + px;
     out[3 * idx + 0] = col.x;
     out[3 * idx + 1] = col.y;
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_render(Scene sc, RtCamera cam, Ren
 }
 
 // World::color_at for caller-supplied rays (world.rs:91-99).
-template <bool COUNT>
+template <bool COUNT, bool SIMPLE>
 __global__ __launch_bounds__(RT_BLOCK) void k_color_at(Scene sc, RenderParams rp, const float* __restrict__ origins,
                                                   const float* __restrict__ directions, uint32_t n,
                                                   uint32_t remaining, float* __restrict__ out,
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_color_at(Scene sc, RenderParams rp
           v3(directions[3 * i], directions[3 * i + 1], directions[3 * i + 2])};
     cn.primary = 1;
     Hit ph;
-    V3 col = color_at<COUNT>(sc, rp, r, remaining, i, cn, &ph);
+    V3 col = SIMPLE ? color_at_direct<COUNT>(sc, rp, r, remaining, i, cn, &ph) : color_at<COUNT>(sc, rp, r, remaining, i, cn, &ph);
     if (out) {
       out[3 * i] = col.x;
       out[3 * i + 1] = col.y;
@@ -463,7 +464,9 @@ int rt_render_device(RtContext* ctx, const RtDeviceScene* ds, const RtCamera* ca
     const uint32_t tile = RT_BLOCK == 256 ? 16u : 8u;
     dim3 grid((cam->hsize + tile - 1) / tile, (part.rows + tile - 1) / tile);
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
-    auto kern = (sc.flags & RT_RENDER_COUNT_WORK) ? k_render<true> : k_render<false>;
+    const bool simple = sc.n_nodes == 0;  // no groups: direct integrator (rt_device.h)
+    auto kern = (sc.flags & RT_RENDER_COUNT_WORK) ? (simple ? k_render<true, true> : k_render<true, false>)
+                                                  : (simple ? k_render<false, true> : k_render<false, false>);
     hipLaunchKernelGGL(kern, grid, dim3(RT_BLOCK), 0, stream, sc, *cam, rp, part, d_out_rgb,
                        d_aux ? d_aux->hit_mask : nullptr, d_aux ? d_aux->object_id : nullptr,
                        d_aux ? d_aux->hit_t : nullptr, ctx->d_counters);
@@ -575,7 +578,8 @@ int rt_color_at(RtContext* ctx, const RtDeviceScene* ds, const RtRenderOptions* 
   sc.flags = opts ? opts->flags : 0;
   RenderParams rp = make_params(opts);
   TRY_CLEAN(hipEventRecord(ctx->ev0, ctx->stream));
-  hipLaunchKernelGGL(k_color_at<false>, dim3((n + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, ctx->stream, sc, rp, d_o, d_d, n, remaining,
+  auto ckern = sc.n_nodes == 0 ? k_color_at<false, true> : k_color_at<false, false>;
+  hipLaunchKernelGGL(ckern, dim3((n + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, ctx->stream, sc, rp, d_o, d_d, n, remaining,
                      d_rgb, d_t, d_id, d_uv, ctx->d_counters);
   TRY_CLEAN(hipGetLastError());
   TRY_CLEAN(hipEventRecord(ctx->ev1, ctx->stream));
