@@ -89,10 +89,11 @@ class RtAccelView(C.Structure):
 
 
 AUX_NODE = np.dtype([("lmin", "<f4", 3), ("left", "<u4"), ("lmax", "<f4", 3), ("lcount", "<u4"),
-                     ("rmin", "<f4", 3), ("right", "<u4"), ("rmax", "<f4", 3), ("rcount", "<u4")])
+                     ("rmin", "<f4", 3), ("right", "<u4"), ("rmax", "<f4", 3), ("rcount", "<u4"),
+                     ("cone", "<f4", 4)])
 AUX_TRI = np.dtype([("p1", "<f4", 3), ("shape", "<u4"), ("e1", "<f4", 3), ("owner", "<u4"), ("e2", "<f4", 3),
                     ("kind_flags", "<u4")])
-assert AUX_NODE.itemsize == 64 and AUX_TRI.itemsize == 48
+assert AUX_NODE.itemsize == 80 and AUX_TRI.itemsize == 48
 
 EXPORTS = ["rt_accel_build", "rt_accel_free", "rt_abi_version", "rt_context_create", "rt_context_destroy", "rt_last_error", "rt_scene_create",
            "rt_scene_destroy", "rt_part_rows", "rt_render", "rt_render_device", "rt_color_at"]

@@ -19,11 +19,15 @@
 //      ancestor passes" (monotonicity of the correctly rounded slab arithmetic, for rays with at
 //      least one |d| >= 1e-4 component).  gate_next[] lists the groups whose test is NOT implied.
 //
-// Layout (device, 64 B per node, 16 B aligned):
-//   aux[root]      header: {cx, cy, cz, radius} {lmax, amax, 0, 0} {unused} {unused}
+// Layout (device, 80 B per node, 16 B aligned):
+//   aux[root]      header: {cx, cy, cz, radius} {lmax, amax, 0, 0} {unused} {unused} {unused}
 //                  (centre/radius of the padded boxes, longest edge, largest |e1|*|e2|)
-//   aux[root + 1]  top node; every node holds the boxes of BOTH children:
-//     {lmin.xyz, left}  {lmax.xyz, lcount}  {rmin.xyz, right}  {rmax.xyz, rcount}
+//   aux[root + 1]  top node; every node holds the boxes of BOTH children and its own normal cone:
+//     {lmin.xyz, left}  {lmax.xyz, lcount}  {rmin.xyz, right}  {rmax.xyz, rcount}  {a.xyz, cos w}
+//     cone: every triangle below the node has its unit normal within angle w of a/|a|, and
+//     1/sin(angle between its edges e1, e2) <= 1/|a|; cos w < -1 means "no bound".  The traversal turns
+//     that into a bound on K = |e1||e2||d|/|det| = 1/(sin(e1,e2) |cos(d, normal)|) for the node, which
+//     sets how far its child boxes must be widened for this ray (rule 1).
 //     count == 0: child is the node aux[left]; count > 0: child is the leaf
 //     aux_tris[left .. left+count), 3 float4 per triangle:
 //       {p1.xyz, shape index} {e1.xyz, owning node index} {e2.xyz, shape kind_flags}   (as uint bits)
@@ -56,8 +60,9 @@ struct Node {
   uint32_t right;
   float rmax[3];
   uint32_t rcount;
+  float cone[4];
 };
-static_assert(sizeof(Node) == 64, "aux node is 64 B");
+static_assert(sizeof(Node) == 80, "aux node is 80 B");
 struct Tri {
   float p1[3];
   uint32_t shape;
@@ -80,6 +85,8 @@ struct Item {
   uint32_t tri;    // index into RtScene::tri_geom
   uint32_t shape;  // index into RtScene::shapes
   uint32_t owner;  // node index
+  float nrm[3];    // unit normal (zero if degenerate)
+  float kalpha;    // 1 / sin(angle(e1, e2)), inf if degenerate
 };
 
 struct TreeBuilder {
@@ -109,6 +116,19 @@ struct TreeBuilder {
     for (int a = 0; a < 3; a++) {
       float d = g.e2[a] - g.e1[a];
       l1 += g.e1[a] * g.e1[a], l2 += g.e2[a] * g.e2[a], l3 += d * d;
+    }
+    {
+      double e1[3] = {g.e1[0], g.e1[1], g.e1[2]}, e2[3] = {g.e2[0], g.e2[1], g.e2[2]};
+      double c[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+      double cl = std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+      double sina = cl / (std::sqrt((double)l1) * std::sqrt((double)l2));
+      if (cl > 0 && std::isfinite(sina) && sina > 1e-5) {
+        for (int a = 0; a < 3; a++) it.nrm[a] = (float)(c[a] / cl);
+        it.kalpha = (float)(1.0 / sina);
+      } else {
+        it.nrm[0] = it.nrm[1] = it.nrm[2] = 0.f;
+        it.kalpha = INFINITY;
+      }
     }
     float edge = std::sqrt(std::max(l1, std::max(l2, l3)));
     lmax = std::max(lmax, edge);
@@ -170,6 +190,29 @@ struct TreeBuilder {
     *ref = me;
     *count = 0;
     Node nd{};
+    {  // normal cone of [b,e): axis = normalised sum of the unit normals, half-angle = largest deviation
+      double ax[3] = {0, 0, 0}, kmax = 0;
+      bool ok = true;
+      for (uint32_t i = b; i < e && ok; i++) {
+        ok = std::isfinite(items[i].kalpha);
+        kmax = std::max(kmax, (double)items[i].kalpha);
+        for (int a = 0; a < 3; a++) ax[a] += items[i].nrm[a];
+      }
+      double al = std::sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+      nd.cone[0] = nd.cone[1] = nd.cone[2] = 0.f;
+      nd.cone[3] = -2.f;
+      if (ok && al > 1e-6 * n) {
+        double cmin = 1.0;
+        for (uint32_t i = b; i < e; i++)
+          cmin = std::min(cmin, (ax[0] * items[i].nrm[0] + ax[1] * items[i].nrm[1] + ax[2] * items[i].nrm[2]) / al);
+        double w = std::acos(std::max(-1.0, std::min(1.0, cmin))) + 2e-3;  // widened a little: f32 normals
+        if (w < 1.4) {                                                     // < 80 degrees, else no useful bound
+          double inv_k = 1.0 / (kmax * 1.001);
+          for (int a = 0; a < 3; a++) nd.cone[a] = (float)(ax[a] / al * inv_k);
+          nd.cone[3] = (float)std::cos(w);
+        }
+      }
+    }
     build(b, mid, depth + 1, &nd.left, &nd.lcount, nd.lmin, nd.lmax);
     build(mid, e, depth + 1, &nd.right, &nd.rcount, nd.rmin, nd.rmax);
     nodes[me] = nd;

@@ -29,6 +29,7 @@
 #define RT_NODE_HAS_NOSHADOW 0x8u  // device copy only: a shape with shadow() == false lives in this subtree
 #define RT_SCENE_HAS_NOSHADOW 0x1u // Scene::props: some shape has shadow() == false
 #define RT_SCENE_SHADOW_TWO_PASS 0x4u // Scene::props: shadow-less shapes exist AND auxiliary BVHs exist: find F first, then any occluder
+#define RT_SCENE_AREA_LIGHT 0x8u   // Scene::props: some area light takes more than one sample
 #define RT_SCENE_RI_ALL_ONE 0x2u   // Scene::props: every material has refractive_index == 1 (n1 = n2 = 1 always)
 
 namespace rtd {
@@ -83,7 +84,7 @@ struct Scene {
   const RtImage* images;
   const float* texels;
   const RtLight* lights;
-  const float4* aux_nodes;  // library-built auxiliary BVHs (rt_accel.h): 4 float4 per node
+  const float4* aux_nodes;  // library-built auxiliary BVHs (rt_accel.h): 5 float4 per node
   const float4* aux_tris;   // their leaf triangles: 3 float4 per triangle, p1.w = offset in the group
   uint32_t n_shapes, n_nodes, n_csg_roots, n_lights, n_loose, recursion_limit;
   uint32_t flags;  // RT_RENDER_*
@@ -586,7 +587,7 @@ __device__ inline bool aux_intersect(const Scene& sc, uint32_t root_node, uint32
   // the nesting argument behind aux_gate needs one axis on the non-parallel branch of check_axis
   if (!(__builtin_fabsf(cur.d.x) >= 1e-4f || __builtin_fabsf(cur.d.y) >= 1e-4f || __builtin_fabsf(cur.d.z) >= 1e-4f))
     return false;
-  const float4* A = sc.aux_nodes + 4u * (size_t)aux_root;
+  const float4* A = sc.aux_nodes + 5u * (size_t)aux_root;
   float4 h0 = A[0], h1 = A[1];
   // Ray-dependent widening (DESIGN.md "Auxiliary BVH"): in f32 the reference's triangle test accepts a
   // line that passes the triangle's plane up to 16u * K * (|s| + L) outside it (u = 2^-24,
@@ -596,22 +597,49 @@ __device__ inline bool aux_intersect(const Scene& sc, uint32_t root_node, uint32
   V3 oc = cur.o - v3(h0.x, h0.y, h0.z);
   float S = magnitude(oc) + h0.w;
   float dm = magnitude(cur.d);
-  float pad = (0.0143f * h1.y) * (dm * (S + h1.x));
-  if (!(pad < h0.w)) return false;  // NaN/inf, or wider than the whole tree
+  // pad = 1.5 * 16u * K * (S + L): K <= kmax from the |det| >= 1e-4 rule of the triangle test; per node the normal
+  // cone gives the usually far smaller bound K <= 1 / (sin(e1,e2) * |cos(d, normal)|)
+  const float kmax = 1e4f * h1.y * dm;
+  const float padk = 1.43e-6f * (S + h1.x);  // 1.5 * 16 * 2^-24 * (S + L)
+  if (!(padk * kmax < h0.w)) return false;   // NaN/inf, or wider than the whole tree
+  const V3 dn = cur.d / dm;
   V3 inv = v3(__builtin_amdgcn_rcpf(cur.d.x), __builtin_amdgcn_rcpf(cur.d.y), __builtin_amdgcn_rcpf(cur.d.z));
   uint32_t* stk = aux_stack();
   int sp = 0;
   uint32_t ref = (aux_root + 1u) << 3;
   // the computed t of an accepted hit lies within 13u * K * |s| / |d| < 0.55 * pad / |d| of the line's true
   // crossing of the triangle's plane, which is inside the widened box: slack for the t-range pruning
-  const float tpad = pad / dm;
-  const float lo = (sink.wants_negative() ? -__builtin_inff() : 0.f) - tpad;
+  const float lo0 = sink.wants_negative() ? -__builtin_inff() : 0.f;
   while (true) {
     uint32_t cnt = ref & 7u, idx = ref >> 3;
     if (cnt == 0u) {
-      const float4* N = sc.aux_nodes + 4u * (size_t)idx;
-      float4 n0 = N[0], n1 = N[1], n2 = N[2], n3 = N[3];
+      const float4* N = sc.aux_nodes + 5u * (size_t)idx;
+      float4 n0 = N[0], n1 = N[1], n2 = N[2], n3 = N[3], n4 = N[4];
       if (COUNT) cn.aux_tests += 2;
+      float kb = kmax;
+#ifndef RT_CONE_MODE
+#define RT_CONE_MODE 2
+#endif
+#if RT_CONE_MODE == 0
+      if (n4.w > 3.f) kb = 0.f;
+#else
+#if RT_CONE_MODE == 1
+#define RT_SQRT __builtin_sqrtf
+#else
+#define RT_SQRT __builtin_amdgcn_sqrtf
+#endif
+      if (n4.w >= -1.f) {  // cone: |cos(d, normal)| >= cos(phi + w) for every triangle below, phi = angle(d, axis)
+        float ik2 = n4.x * n4.x + n4.y * n4.y + n4.z * n4.z;                  // (1 / max(1/sin(e1,e2)))^2
+        float cp = __builtin_fabsf(dn.x * n4.x + dn.y * n4.y + dn.z * n4.z);  // cos(phi) / kalpha
+        float sw = RT_SQRT(__builtin_fmaxf(0.f, 1.f - n4.w * n4.w));
+        float q = cp * n4.w - RT_SQRT(__builtin_fmaxf(0.f, ik2 - cp * cp)) * sw;  // cos(phi+w) / kalpha
+        // rounding (worst where ik2 - cp^2 cancels) moves q by < 4e-4 / kalpha: under 4 % of a q that passes
+        if (q > 0.f && q * q > 1e-4f * ik2) kb = __builtin_fminf(kmax, __builtin_amdgcn_rcpf(q) * 1.06f);
+      }
+#endif
+      const float pad = padk * kb;
+      const float tpad = pad / dm;
+      const float lo = lo0 - tpad;
       float lim = sink.limit();
       float hi = (lim + 1e-5f * __builtin_fabsf(lim)) + tpad;
       float tl, tr;
@@ -680,8 +708,11 @@ __device__ inline Ray ray_in_space_of(const Scene& sc, int xf_node, const Ray& w
 // that sat the visit out wait for something >= skip(i); so the next uniform index is i+1 if any lane
 // descends and skip(i) otherwise.
 __device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+#ifndef RT_WI_INLINE
+#define RT_WI_INLINE inline
+#endif
 template <bool COUNT>
-__device__ inline void world_intersect(const Scene& sc, const Ray& ray, Sink& sink, Counters& cn) {
+__device__ RT_WI_INLINE void world_intersect(const Scene& sc, const Ray& ray, Sink& sink, Counters& cn) {
   // csgs first (world.rs:45-49)
   if (sc.n_csg_roots) {
     CsgList L;

@@ -51,11 +51,20 @@ __device__ __forceinline__ void flush_counters(const Counters& cn, unsigned long
 
 // Camera::render (camera.rs:66-84): one lane per pixel, one wave per 8x8 pixel tile, four waves
 // per 16x16 block.  Rows are the interleaved scanline tiles of this part.
+// Two kernel families share the pixel body:
+//   k_render_jobs    job-loop integrator (rt_device.h color_at).  Register budget capped at 128 VGPRs so four
+//                    waves share a SIMD: the traversal is a chain of dependent loads and at the compiler's natural
+//                    ~200 VGPRs (two waves) the SIMDs sat idle more than half the time (profiles/README.md).
+//   k_render_direct  direct integrator (color_at_direct) for group-less worlds whose cost is the shadow-sample
+//                    loop of an area light.
+#ifndef RT_WAVES_PER_EU
+#define RT_WAVES_PER_EU 4
+#endif
 template <bool COUNT, bool SIMPLE>
-__global__ __launch_bounds__(RT_BLOCK) void k_render(Scene sc, RtCamera cam, RenderParams rp, PartInfo part,
-                                                float* __restrict__ out, uint8_t* __restrict__ mask,
-                                                int32_t* __restrict__ oid, float* __restrict__ ht,
-                                                unsigned long long* counters) {
+__device__ __forceinline__ void render_pixel(const Scene& sc, const RtCamera& cam, const RenderParams& rp,
+                                             const PartInfo& part, float* __restrict__ out, uint8_t* __restrict__ mask,
+                                             int32_t* __restrict__ oid, float* __restrict__ ht,
+                                             unsigned long long* counters) {
   const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
 #if RT_BLOCK == 256
   const uint32_t px = blockIdx.x * 16u + (wave & 1u) * 8u + (lane & 7u);
@@ -96,6 +105,20 @@ __global__ __launch_bounds__(RT_BLOCK) void k_render(Scene sc, RtCamera cam, Ren
     }
   }
   flush_counters(cn, counters);
+}
+template <bool COUNT>
+__global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAVES_PER_EU, RT_WAVES_PER_EU)))
+void k_render_jobs(Scene sc, RtCamera cam, RenderParams rp, PartInfo part, float* __restrict__ out,
+                   uint8_t* __restrict__ mask, int32_t* __restrict__ oid, float* __restrict__ ht,
+                   unsigned long long* counters) {
+  render_pixel<COUNT, false>(sc, cam, rp, part, out, mask, oid, ht, counters);
+}
+template <bool COUNT>
+__global__ __launch_bounds__(RT_BLOCK)
+void k_render_direct(Scene sc, RtCamera cam, RenderParams rp, PartInfo part, float* __restrict__ out,
+                     uint8_t* __restrict__ mask, int32_t* __restrict__ oid, float* __restrict__ ht,
+                     unsigned long long* counters) {
+  render_pixel<COUNT, true>(sc, cam, rp, part, out, mask, oid, ht, counters);
 }
 
 // World::color_at for caller-supplied rays (world.rs:91-99).
@@ -367,6 +390,8 @@ int rt_scene_create(RtContext* ctx, const RtScene* s, RtDeviceScene** out) {
     bool ri_one = true;
     for (uint32_t i = 0; i < s->n_materials; i++) ri_one = ri_one && s->materials[i].refractive_index == 1.0f;
     if (ri_one) d.props |= RT_SCENE_RI_ALL_ONE;
+    for (uint32_t i = 0; i < s->n_lights; i++)
+      if (s->lights[i].kind == RT_LIGHT_AREA && s->lights[i].usteps * s->lights[i].vsteps > 1) d.props |= RT_SCENE_AREA_LIGHT;
     if ((d.props & RT_SCENE_HAS_NOSHADOW) && !acc.nodes.empty()) d.props |= RT_SCENE_SHADOW_TWO_PASS;
     for (uint32_t i = 0; i < s->n_nodes; i++) {
       if (acc.root_of[i] != rtaccel::kNone) {
@@ -464,9 +489,10 @@ int rt_render_device(RtContext* ctx, const RtDeviceScene* ds, const RtCamera* ca
     const uint32_t tile = RT_BLOCK == 256 ? 16u : 8u;
     dim3 grid((cam->hsize + tile - 1) / tile, (part.rows + tile - 1) / tile);
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
-    const bool simple = sc.n_nodes == 0;  // no groups: direct integrator (rt_device.h)
-    auto kern = (sc.flags & RT_RENDER_COUNT_WORK) ? (simple ? k_render<true, true> : k_render<true, false>)
-                                                  : (simple ? k_render<false, true> : k_render<false, false>);
+    // both integrators give the same bits; the direct one wins where an area light's sample loop dominates
+    const bool direct = sc.n_nodes == 0 && (sc.props & RT_SCENE_AREA_LIGHT);
+    auto kern = (sc.flags & RT_RENDER_COUNT_WORK) ? (direct ? k_render_direct<true> : k_render_jobs<true>)
+                                                  : (direct ? k_render_direct<false> : k_render_jobs<false>);
     hipLaunchKernelGGL(kern, grid, dim3(RT_BLOCK), 0, stream, sc, *cam, rp, part, d_out_rgb,
                        d_aux ? d_aux->hit_mask : nullptr, d_aux ? d_aux->object_id : nullptr,
                        d_aux ? d_aux->hit_t : nullptr, ctx->d_counters);
