@@ -559,8 +559,10 @@ __device__ __forceinline__ bool aux_box(V3 o, V3 inv, float pad, float4 mn, floa
   float az = ((mn.z - pad) - o.z) * inv.z, bz = ((mx.z + pad) - o.z) * inv.z;
   float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz));
   float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz));
-  tn = tn - 2e-6f * __builtin_fabsf(tn);
-  tf = tf + 2e-6f * __builtin_fabsf(tf);
+  // relative slack; fmin/fmax drop the NaN of inf - inf (a ray parallel to a slab it lies outside of has
+  // tn = +inf or tf = -inf and must stay a miss, not turn into "NaN = inside")
+  tn = __builtin_fminf(tn, tn - 2e-6f * __builtin_fabsf(tn));
+  tf = __builtin_fmaxf(tf, tf + 2e-6f * __builtin_fabsf(tf));
   tnear = tn;
   return !(tn > tf) && !(tn > hi) && !(tf < lo);
 }
@@ -601,7 +603,9 @@ __device__ inline bool aux_intersect(const Scene& sc, uint32_t root_node, uint32
   // cone gives the usually far smaller bound K <= 1 / (sin(e1,e2) * |cos(d, normal)|)
   const float kmax = 1e4f * h1.y * dm;
   const float padk = 1.43e-6f * (S + h1.x);  // 1.5 * 16 * 2^-24 * (S + L)
-  if (!(padk * kmax < h0.w)) return false;   // NaN/inf, or wider than the whole tree
+  // NaN/inf rays take the reference walk.  A worst-case pad wider than the tree is fine: it only applies below
+  // nodes without a cone bound, and the walk through them is still no longer than the reference's.
+  if (!(padk * kmax < __builtin_inff())) return false;
   const V3 dn = cur.d / dm;
   V3 inv = v3(__builtin_amdgcn_rcpf(cur.d.x), __builtin_amdgcn_rcpf(cur.d.y), __builtin_amdgcn_rcpf(cur.d.z));
   uint32_t* stk = aux_stack();

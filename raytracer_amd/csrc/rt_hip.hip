@@ -604,7 +604,8 @@ int rt_color_at(RtContext* ctx, const RtDeviceScene* ds, const RtRenderOptions* 
   sc.flags = opts ? opts->flags : 0;
   RenderParams rp = make_params(opts);
   TRY_CLEAN(hipEventRecord(ctx->ev0, ctx->stream));
-  auto ckern = sc.n_nodes == 0 ? k_color_at<false, true> : k_color_at<false, false>;
+  auto ckern = sc.n_nodes == 0 ? k_color_at<false, true>
+               : (sc.flags & RT_RENDER_COUNT_WORK) ? k_color_at<true, false> : k_color_at<false, false>;
   hipLaunchKernelGGL(ckern, dim3((n + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, ctx->stream, sc, rp, d_o, d_d, n, remaining,
                      d_rgb, d_t, d_id, d_uv, ctx->d_counters);
   TRY_CLEAN(hipGetLastError());
