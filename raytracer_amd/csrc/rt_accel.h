@@ -339,4 +339,5 @@ inline Result build(const RtScene* s) {
   return r;
 }
 
+
 }  // namespace rtaccel

@@ -27,6 +27,9 @@
 #define RT_AUX_NONE 0xFFFFFFFFu
 #define RT_NODE_AUX 0x4u      // device copy only: this node is the root of a subtree covered by an auxiliary BVH
 #define RT_NODE_HAS_NOSHADOW 0x8u  // device copy only: a shape with shadow() == false lives in this subtree
+#ifndef RT_CONE_MIN_PAD
+#define RT_CONE_MIN_PAD 0.125f  // aux BVH: worst-case pad / longest triangle edge above which the cone bound is evaluated
+#endif
 #define RT_SCENE_HAS_NOSHADOW 0x1u // Scene::props: some shape has shadow() == false
 #define RT_SCENE_SHADOW_TWO_PASS 0x4u // Scene::props: shadow-less shapes exist AND auxiliary BVHs exist: find F first, then any occluder
 #define RT_SCENE_AREA_LIGHT 0x8u   // Scene::props: some area light takes more than one sample
@@ -68,7 +71,18 @@ struct Counters {
   // work counters (only maintained by the COUNT instantiations; bench roofline)
   uint32_t node_visits, tri_tests, shape_tests, shaded, xforms, aux_tests;
   uint32_t work_shadow, work_collect;  // COUNT only: tests spent in shadow rays / n1-n2 collect passes
+#ifdef RT_PHASE_TIMERS
+  uint32_t t_iters, t_load;
+  uint32_t t_world, t_aux, t_shapes;   // diagnostics build: wave clock spent in world_intersect / aux BVH / shape tests
+#endif
 };
+#ifdef RT_PHASE_TIMERS
+#define RT_T0(v) const uint64_t v = __builtin_readcyclecounter()
+#define RT_TACC(field, v) cn.field += (uint32_t)(__builtin_readcyclecounter() - v)
+#else
+#define RT_T0(v)
+#define RT_TACC(field, v)
+#endif
 
 struct Scene {
   const RtXform* xforms;
@@ -138,6 +152,33 @@ __device__ __forceinline__ bool slab(const Ray& r, V3 mn, V3 mx, float& tmin, fl
   tmin = of_max(of_max(x0, y0), z0);
   tmax = of_min(of_min(x1, y1), z1);
   return !of_gt(tmin, tmax);
+}
+
+// The same decision (and t-range, to a few ulp) without the six IEEE divisions of check_axis: quotients through
+// v_rcp_f32 are within 4 ulp of the correctly rounded ones, so when the approximate entry and exit values are
+// further apart than that error allows, the reference's comparison tmin > tmax is already decided.  Anything
+// closer, any axis on the "parallel" branch and anything non-finite takes the exact path above.
+__device__ __forceinline__ bool slab_decided(const Ray& r, V3 mn, V3 mx, float& tmin, float& tmax) {
+  const float ax = __builtin_fabsf(r.d.x), ay = __builtin_fabsf(r.d.y), az = __builtin_fabsf(r.d.z);
+  if (__builtin_fminf(__builtin_fminf(ax, ay), az) >= 1e-4f) {  // false for NaN
+    float ix = __builtin_amdgcn_rcpf(r.d.x), iy = __builtin_amdgcn_rcpf(r.d.y), iz = __builtin_amdgcn_rcpf(r.d.z);
+    float x0 = (mn.x - r.o.x) * ix, x1 = (mx.x - r.o.x) * ix;
+    float y0 = (mn.y - r.o.y) * iy, y1 = (mx.y - r.o.y) * iy;
+    float z0 = (mn.z - r.o.z) * iz, z1 = (mx.z - r.o.z) * iz;
+    float lo = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x0, x1), __builtin_fminf(y0, y1)), __builtin_fminf(z0, z1));
+    float hi = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x0, x1), __builtin_fmaxf(y0, y1)), __builtin_fmaxf(z0, z1));
+    float big = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(x0), __builtin_fabsf(x1)),
+                                                __builtin_fmaxf(__builtin_fabsf(y0), __builtin_fabsf(y1))),
+                                __builtin_fmaxf(__builtin_fabsf(z0), __builtin_fabsf(z1)));
+    float e = 1e-6f * big;  // 4 ulp of the largest quotient, twice over
+    if (lo - hi > e) return false;  // certain miss (tmin, tmax unused)
+    if (hi - lo > e) {              // certain hit
+      tmin = lo;
+      tmax = hi;
+      return true;
+    }
+  }
+  return slab(r, mn, mx, tmin, tmax);
 }
 
 // Local intersections: fill ts[] in the reference's insertion order, return the count.
@@ -607,6 +648,9 @@ __device__ inline bool aux_intersect(const Scene& sc, uint32_t root_node, uint32
   // nodes without a cone bound, and the walk through them is still no longer than the reference's.
   if (!(padk * kmax < __builtin_inff())) return false;
   const V3 dn = cur.d / dm;
+  // the cone bound costs a fifth load and ~25 operations per node: only worth it when the worst-case pad is not
+  // already small against the tree's triangles
+  const bool use_cone = padk * kmax > RT_CONE_MIN_PAD * h1.x;
   V3 inv = v3(__builtin_amdgcn_rcpf(cur.d.x), __builtin_amdgcn_rcpf(cur.d.y), __builtin_amdgcn_rcpf(cur.d.z));
   uint32_t* stk = aux_stack();
   int sp = 0;
@@ -618,9 +662,11 @@ __device__ inline bool aux_intersect(const Scene& sc, uint32_t root_node, uint32
     uint32_t cnt = ref & 7u, idx = ref >> 3;
     if (cnt == 0u) {
       const float4* N = sc.aux_nodes + 5u * (size_t)idx;
-      float4 n0 = N[0], n1 = N[1], n2 = N[2], n3 = N[3], n4 = N[4];
+      float4 n0 = N[0], n1 = N[1], n2 = N[2], n3 = N[3];
       if (COUNT) cn.aux_tests += 2;
       float kb = kmax;
+      float4 n4 = make_float4(0.f, 0.f, 0.f, -2.f);
+      if (use_cone) n4 = N[4];
 #ifndef RT_CONE_MODE
 #define RT_CONE_MODE 2
 #endif
@@ -716,9 +762,11 @@ __device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballo
 #define RT_WI_INLINE inline
 #endif
 template <bool COUNT>
-__device__ RT_WI_INLINE void world_intersect(const Scene& sc, const Ray& ray, Sink& sink, Counters& cn) {
+__device__ RT_WI_INLINE void world_intersect(const Scene& sc, const Ray& ray, Sink& sink, Counters& cn,
+                                             const bool active = true) {
+  // `active` false: this lane has no ray to trace but still takes part in the wave-wide votes of the walk
   // csgs first (world.rs:45-49)
-  if (sc.n_csg_roots) {
+  if (sc.n_csg_roots && active) {
     CsgList L;
     L.overflow = 0;
     for (uint32_t c = 0; c < sc.n_csg_roots; c++) {
@@ -733,12 +781,18 @@ __device__ RT_WI_INLINE void world_intersect(const Scene& sc, const Ray& ray, Si
     Ray cur = ray;
     uint32_t leave_at = 0xFFFFFFFFu;  // first node outside the innermost transformed subtree this lane is in
     const bool prune = !(sc.flags & RT_RENDER_NO_PRUNE);
-    uint32_t my_i = 0;                // the node this lane visits next
+    uint32_t my_i = active ? 0u : 0xFFFFFFFFu;  // the node this lane visits next
     uint32_t i = 0;                   // wave-uniform
     while (i < sc.n_nodes) {
       i = __builtin_amdgcn_readfirstlane(i);
       const uint4* raw = reinterpret_cast<const uint4*>(sc.nodes + i);
+      RT_T0(tl);
       uint4 w0 = raw[0], w1 = raw[1], w2 = raw[2], w3 = raw[3];
+#ifdef RT_PHASE_TIMERS
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      RT_TACC(t_load, tl);
+      cn.t_iters++;
+#endif
       const uint32_t xform = w0.w, flags = w1.w, skip = w2.z;
       bool descend = false;
       if (sink.done()) my_i = 0xFFFFFFFFu;  // an occluder is enough (any-shadow): this lane is finished
@@ -761,7 +815,7 @@ __device__ RT_WI_INLINE void world_intersect(const Scene& sc, const Ray& ray, Si
         float tmin, tmax;
         V3 bmin = v3(__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z));
         V3 bmax = v3(__uint_as_float(w1.x), __uint_as_float(w1.y), __uint_as_float(w1.z));
-        descend = slab(cur, bmin, bmax, tmin, tmax);  // groups.rs:111-113
+        descend = slab_decided(cur, bmin, bmax, tmin, tmax);  // groups.rs:111-113
         if (descend && prune && (flags & RT_NODE_PRUNABLE)) {
           // Distance pruning (not in the reference): a box that truly encloses its subtree cannot
           // hold a hit beyond its exit or before its entry; margins cover f32 rounding of t.
@@ -770,11 +824,14 @@ __device__ RT_WI_INLINE void world_intersect(const Scene& sc, const Ray& ray, Si
           if (!sink.wants_negative() && tmax < -(1e-4f * __builtin_fabsf(tmax) + 1e-4f)) descend = false;
         }
         // device copy of a node: the slot of n_children holds the auxiliary BVH of the subtree (RT_NODE_AUX)
+        RT_T0(ta);
         if (descend && (flags & RT_NODE_AUX) && !(sc.flags & RT_RENDER_NO_ACCEL) &&
             aux_intersect<COUNT>(sc, i, w3.w, cur, sink, cn))
           descend = false;
+        RT_TACC(t_aux, ta);
       }
       if (wave_any(descend)) {
+        RT_T0(ts);
         const uint32_t first_shape = w2.x, n_shapes = w2.y;
         if (flags & RT_NODE_ALL_TRIS) {
           if (COUNT && descend) cn.tri_tests += n_shapes;
@@ -790,6 +847,7 @@ __device__ RT_WI_INLINE void world_intersect(const Scene& sc, const Ray& ray, Si
           for (uint32_t k = 0; k < n_shapes; k++)
             if (descend) shape_intersect(sc, first_shape + k, cur, sink);
         }
+        RT_TACC(t_shapes, ts);
         if (my_i == i) my_i = descend ? i + 1u : skip;
         i = i + 1u;
       } else {
@@ -800,9 +858,9 @@ __device__ RT_WI_INLINE void world_intersect(const Scene& sc, const Ray& ray, Si
     }
   }
   // loose shapes (world.rs:56-59): the last n_loose entries of shapes[]
-  if (COUNT) cn.shape_tests += sc.n_loose;
+  if (COUNT && active) cn.shape_tests += sc.n_loose;
   for (uint32_t k = sc.n_shapes - sc.n_loose; k < sc.n_shapes; k++)
-    if (!sink.done()) shape_intersect(sc, k, ray, sink);
+    if (active && !sink.done()) shape_intersect(sc, k, ray, sink);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1120,41 +1178,117 @@ __device__ inline void refractive_indices(const Scene& sc, float* ts, uint32_t* 
   }
 }
 
-template <bool COUNT>
-__device__ inline V3 color_at(const Scene& sc, const RenderParams& rp, Ray primary, uint32_t remaining0,
-                              uint32_t pixel, Counters& cn, Hit* primary_hit) {
+// Register budget: the traversal alone needs ~100 VGPRs and the kernel is built for 128 (four waves per SIMD), so the
+// shading state must not ride through the traversal in registers.  What prepare() derived from a hit is kept in its
+// smallest form -- the shaded ray, t, the normal, the material index -- and eyev, point, over_point, under_point,
+// reflectv and the material parameters are recomputed/reloaded where they are used (same expressions => same bits).
+// The values only touched between traversals (accumulators, the shaded ray, the pattern colour) are parked in LDS.
+enum { PK_RESULT = 0, PK_SRAY_O = 3, PK_SRAY_D = 6, PK_SURFACE = 9, PK_MCOLOR = 12, PK_WEIGHT = 15, PK_SLOTS = 16 };
+// accessors take the lane's slot offset (threadIdx.x), so the LDS address space stays visible to the compiler
+struct Park {
+  uint32_t off;
+  __device__ __forceinline__ float* base() const {
+    __shared__ float park[PK_SLOTS * RT_BLOCK];
+    return park;
+  }
+};
+__device__ __forceinline__ float pk_ld(const Park& pk, int k) { return pk.base()[k * RT_BLOCK + pk.off]; }
+__device__ __forceinline__ void pk_st(const Park& pk, int k, float x) { pk.base()[k * RT_BLOCK + pk.off] = x; }
+__device__ __forceinline__ V3 pk_ld3(const Park& pk, int k) { return v3(pk_ld(pk, k), pk_ld(pk, k + 1), pk_ld(pk, k + 2)); }
+__device__ __forceinline__ void pk_st3(const Park& pk, int k, V3 x) {
+  pk_st(pk, k, x.x);
+  pk_st(pk, k + 1, x.y);
+  pk_st(pk, k + 2, x.z);
+}
+
+// Persistent waves: a lane that finishes its pixel (or ray) does not wait for the slowest lane of its wave; it goes
+// idle, and once RT_REFILL_MIN lanes of the wave are idle they take the next items of the work queue together (one
+// atomic per refill; consecutive items are neighbouring pixels of an 8x8 tile).  Per-pixel work varies by three orders
+// of magnitude in the dragons scene, so this is what keeps lanes busy and what removes the long tail of a frame.
+// `Source` supplies the work: total(), start(item, ray, id) -> false if the item is outside the image, and
+// finish(item, colour, primary hit, work).  `queue` is a zeroed counter in device memory.
+// Every wave leaves the loop: each refill advances the queue, and a wave whose lanes are all idle either refills
+// or, once the queue has run past total(), breaks.
+#ifndef RT_REFILL_MIN
+#define RT_REFILL_MIN 16
+#endif
+enum { ST_IDLE = 100 };
+template <bool COUNT, class Source>
+__device__ inline void integrate(const Scene& sc, const RenderParams& rp, const Source& src, uint32_t remaining0,
+                                 unsigned long long* queue, Counters& cn) {
   PendingRay stack[RT_MAX_RAY_STACK];
   float xs_t[RT_XS_CAP];
   uint32_t xs_s[RT_XS_CAP];
+  Park pk{threadIdx.x};
   int sp = 0;
-  V3 result = v3(0.f, 0.f, 0.f);
   bool first = true;
   const float nl = (float)sc.n_lights;
+  const uint32_t n_items = src.total();
+  bool exhausted = false;  // wave-uniform: the queue has run past the last item
+  uint32_t item = 0, pixel = 0, work_start = 0;
+  Hit primary_hit{0.f, 0.f, 0.f, -1};
 
-  // the ray being shaded (JOB_SHADE) and what prepare() derived from its hit
-  Ray sray = primary;
-  float weight = 1.f;
-  uint32_t remaining = remaining0, path = 1u;
-  Hit hit{0.f, 0.f, 0.f, -1};
-  V3 eyev = v3(0.f, 0.f, 0.f), normalv = eyev, reflectv = eyev, over_point = eyev, under_point = eyev, mcolor = eyev;
-  float m_ambient = 0.f, m_diffuse = 0.f, m_specular = 0.f, m_shininess = 0.f, m_reflective = 0.f, m_transparency = 0.f;
+  // the hit being shaded: with the parked ray, enough to rebuild what Computations::prepare holds
+  uint32_t remaining = 0u, path = 1u;
+  float hit_t = 0.f;
+  int hit_shape = -1;
+  V3 normalv = v3(0.f, 0.f, 0.f);
+  uint32_t mat_id = 0;
   // light loop
   uint32_t li = 0, sample = 0;
   float total = 0.f, distance = 0.f;
-  V3 surface_sum = v3(0.f, 0.f, 0.f);
   float n1 = 1.f, n2 = 1.f;
   float shadow_tF = __builtin_inff();
   int shadow_sF = -1;
 
   // the ray to trace next
-  Ray tray = primary;
+  Ray tray{v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 1.f)};
   int job = JOB_SHADE;
-  int st = ST_TRACE;
-  while (st != ST_DONE) {
+  int st = ST_IDLE;
+  while (true) {
+    // ---------------- refill idle lanes from the queue ----------------
+    {
+      const unsigned long long idle = __builtin_amdgcn_ballot_w64(st == ST_IDLE);
+      const uint32_t n_idle = (uint32_t)__builtin_popcountll(idle);
+      if (!exhausted && (n_idle >= RT_REFILL_MIN || n_idle == (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(true)))) {
+        unsigned long long base = 0;
+        const uint32_t lane = threadIdx.x & 63u;
+        if (lane == (uint32_t)__builtin_ctzll(idle)) base = atomicAdd(queue, (unsigned long long)n_idle);
+        base = ((unsigned long long)__builtin_amdgcn_readlane((int)(base >> 32), __builtin_ctzll(idle)) << 32) |
+               (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)base, __builtin_ctzll(idle));
+        if (base + n_idle >= n_items) exhausted = true;
+        if (st == ST_IDLE) {
+          const uint32_t rank = (uint32_t)__builtin_popcountll(idle & ((1ull << lane) - 1ull));
+          const unsigned long long want = base + rank;
+          Ray primary;
+          if (want < n_items && src.start((uint32_t)want, primary, pixel)) {
+            item = (uint32_t)want;
+            cn.primary++;
+            pk_st3(pk, PK_RESULT, v3(0.f, 0.f, 0.f));
+            pk_st3(pk, PK_SRAY_O, primary.o);
+            pk_st3(pk, PK_SRAY_D, primary.d);
+            pk_st(pk, PK_WEIGHT, 1.f);
+            remaining = remaining0;
+            path = 1u;
+            first = true;
+            sp = 0;
+            tray = primary;
+            job = JOB_SHADE;
+            st = ST_TRACE;
+            if (COUNT) work_start = cn.node_visits + cn.aux_tests + cn.tri_tests + cn.shape_tests;
+          }
+        }
+      }
+      if (!wave_any(st != ST_IDLE)) {
+        if (exhausted) break;
+        continue;  // a refill that only drew items outside the image: draw again
+      }
+    }
+    const bool active = st != ST_IDLE;
     // ---------------- the one traversal ----------------
     Sink sink;
     if (job == JOB_COLLECT)
-      sink.init_collect(xs_t, xs_s, hit.t);
+      sink.init_collect(xs_t, xs_s, hit_t);
     else if (job == JOB_SHADOW && (sc.props & RT_SCENE_HAS_NOSHADOW) && !(sc.props & RT_SCENE_SHADOW_TWO_PASS)) {
       sink.init_closest();  // small scene with shadow-less shapes: one closest-hit pass, capped at the light
       sink.tcap = distance;
@@ -1165,7 +1299,13 @@ __device__ inline V3 color_at(const Scene& sc, const RenderParams& rp, Ray prima
     else
       sink.init_closest();
     const uint32_t work0 = COUNT ? cn.node_visits + cn.aux_tests + cn.tri_tests + cn.shape_tests : 0u;
-    world_intersect<COUNT>(sc, tray, sink, cn);
+    RT_T0(tw);
+    world_intersect<COUNT>(sc, tray, sink, cn, active);
+    RT_TACC(t_world, tw);
+    // parked values are re-read after the traversal, not carried through it in registers: the pointer is laundered
+    // so that loads below cannot be forwarded from the stores above (a "memory" clobber would do the same but also
+    // turns the walk's scalar loads into vector loads)
+    asm volatile("" : "+v"(pk.off));
     if (COUNT) {
       uint32_t dw = cn.node_visits + cn.aux_tests + cn.tri_tests + cn.shape_tests - work0;
       if (job == JOB_SHADOW || job == JOB_SHADOW_F) cn.work_shadow += dw;
@@ -1173,20 +1313,26 @@ __device__ inline V3 color_at(const Scene& sc, const RenderParams& rp, Ray prima
     }
 
     // ---------------- what the traced ray was for ----------------
-    if (job == JOB_SHADE) {
-      hit = Hit{sink.t, sink.u, sink.v, sink.shape};
+    if (!active) {
+      // idle lane: nothing was traced for it
+    } else if (job == JOB_SHADE) {
+      Hit hit = Hit{sink.t, sink.u, sink.v, sink.shape};
       if (first) {
-        if (primary_hit) *primary_hit = hit;
+        primary_hit = hit;
         first = false;
       }
+      hit_t = hit.t;
+      hit_shape = hit.shape;
       if (hit.shape < 0) {
         st = ST_NEXT_RAY;
       } else {
         if (COUNT) cn.shaded++;
         // ---- Computations::prepare (intersections.rs:121-139) ----
+        const Ray sray{pk_ld3(pk, PK_SRAY_O), pk_ld3(pk, PK_SRAY_D)};
         const uint4* raw = reinterpret_cast<const uint4*>(sc.shapes + hit.shape);
         uint4 w0 = raw[0], w1 = raw[1];
-        uint32_t kf = w0.x, sxf = w0.y, mat_id = w0.z, prim = w1.y;
+        uint32_t kf = w0.x, sxf = w0.y, prim = w1.y;
+        mat_id = w0.z;
         int parent = (int)w0.w;
         float smn = __uint_as_float(w1.z), smx = __uint_as_float(w1.w);
         if ((kf & RT_SHAPE_KIND_MASK) == RT_SMOOTH_TRIANGLE && hit.u != hit.u) {
@@ -1199,17 +1345,14 @@ __device__ inline V3 color_at(const Scene& sc, const RenderParams& rp, Ray prima
           isect_triangle(local, p1, e1, e2, tt, hit.u, hit.v);
         }
         V3 point = sray.o + hit.t * sray.d;
-        eyev = -sray.d;
+        V3 eyev = -sray.d;
         V3 lp = world_to_object(sc, sxf, parent, point);
         V3 ln = local_normal_at(sc, kf, smn, smx, prim, lp, hit.u, hit.v);
         normalv = normal_to_world(sc, sxf, parent, ln);
         if (dot(normalv, eyev) < 0.f) normalv = -normalv;
-        reflectv = reflect(sray.d, normalv);
-        over_point = point + 1e-4f * normalv;
-        under_point = point - 1e-4f * normalv;
+        V3 over_point = point + 1e-4f * normalv;
         const RtMaterial& m = sc.materials[mat_id];
-        m_ambient = m.ambient, m_diffuse = m.diffuse, m_specular = m.specular, m_shininess = m.shininess;
-        m_reflective = m.reflective, m_transparency = m.transparency;
+        V3 mcolor;
         if (m.pattern >= 0) {  // pattern_at_shape at over_point (patterns.rs:79-91, world.rs:72)
           const RtPattern& pat = sc.patterns[m.pattern];
           V3 op = world_to_object(sc, sxf, parent, over_point);
@@ -1218,8 +1361,9 @@ __device__ inline V3 color_at(const Scene& sc, const RenderParams& rp, Ray prima
         } else {
           mcolor = v3(m.color[0], m.color[1], m.color[2]);
         }
+        pk_st3(pk, PK_MCOLOR, mcolor);
         // ---- World::shade_hit (world.rs:64-89): direct lighting, summed over lights ----
-        surface_sum = v3(0.f, 0.f, 0.f);
+        pk_st3(pk, PK_SURFACE, v3(0.f, 0.f, 0.f));
         li = 0;
         sample = 0;
         total = 0.f;
@@ -1236,9 +1380,15 @@ __device__ inline V3 color_at(const Scene& sc, const RenderParams& rp, Ray prima
                           ? sink.found
                           : (sink.shape >= 0 && sink.t < distance && (sc.shapes[sink.shape].kind_flags & RT_SHAPE_SHADOW));
       const RtLight& L = sc.lights[li];
+      const RtMaterial& m = sc.materials[mat_id];
+      const float m_ambient = m.ambient, m_diffuse = m.diffuse, m_specular = m.specular, m_shininess = m.shininess;
+      const Ray sray{pk_ld3(pk, PK_SRAY_O), pk_ld3(pk, PK_SRAY_D)};
+      const V3 eyev = -sray.d;
+      const V3 over_point = (sray.o + hit_t * sray.d) + 1e-4f * normalv;
       V3 lcol = v3(L.intensity[0], L.intensity[1], L.intensity[2]);
-      V3 effective = mulc(mcolor, lcol);
+      V3 effective = mulc(pk_ld3(pk, PK_MCOLOR), lcol);
       V3 ambient = m_ambient * effective;
+      V3 surface_sum = pk_ld3(pk, PK_SURFACE);
       if (L.kind == RT_LIGHT_POINT) {
         V3 lpos = v3(L.position[0], L.position[1], L.position[2]);
         float intensity = shadowed ? 0.f : 1.f;  // lights.rs:50-56
@@ -1246,6 +1396,7 @@ __device__ inline V3 color_at(const Scene& sc, const RenderParams& rp, Ray prima
         phong_sample(lpos, over_point, eyev, normalv, effective, lcol, m_diffuse, m_specular, m_shininess, diffuse,
                      specular);
         surface_sum = surface_sum + (ambient + intensity * (diffuse + specular));  // materials.rs:134
+        pk_st3(pk, PK_SURFACE, surface_sum);
         li++;
         st = ST_NEXT_LIGHT;
       } else {
@@ -1270,6 +1421,7 @@ __device__ inline V3 color_at(const Scene& sc, const RenderParams& rp, Ray prima
             }
           sum = (1.f / nb) * sum;
           surface_sum = surface_sum + (ambient + intensity * sum);
+          pk_st3(pk, PK_SURFACE, surface_sum);
           li++;
           sample = 0;
           total = 0.f;
@@ -1278,12 +1430,12 @@ __device__ inline V3 color_at(const Scene& sc, const RenderParams& rp, Ray prima
       }
     } else {  // JOB_COLLECT
       cn.overflow += sink.overflow;
-      refractive_indices(sc, xs_t, xs_s, sink.n, hit.t, hit.shape, n1, n2);
+      refractive_indices(sc, xs_t, xs_s, sink.n, hit_t, hit_shape, n1, n2);
       st = ST_SECONDARY;
     }
 
     // ---------------- advance the shading state until a ray has to be traced ----------------
-    while (st != ST_TRACE && st != ST_DONE) {
+    while (st != ST_TRACE && st != ST_DONE && st != ST_IDLE) {
       if (st == ST_NEXT_LIGHT) {
         if (li < sc.n_lights) {
           const RtLight& L = sc.lights[li];
@@ -1294,6 +1446,7 @@ __device__ inline V3 color_at(const Scene& sc, const RenderParams& rp, Ray prima
             uint32_t u = sample / L.vsteps, v = sample % L.vsteps;  // u outer, v inner (lights.rs:125-126)
             lpos = point_on_light(L, li, u, v, 0u, rp, pixel, path);
           }
+          const V3 over_point = (pk_ld3(pk, PK_SRAY_O) + hit_t * pk_ld3(pk, PK_SRAY_D)) + 1e-4f * normalv;
           V3 v = lpos - over_point;
           distance = magnitude(v);
           tray = Ray{over_point, v / distance};
@@ -1306,13 +1459,14 @@ __device__ inline V3 color_at(const Scene& sc, const RenderParams& rp, Ray prima
           st = ST_LIGHTS_DONE;
         }
       } else if (st == ST_LIGHTS_DONE) {
-        result = result + weight * surface_sum;
+        pk_st3(pk, PK_RESULT, pk_ld3(pk, PK_RESULT) + pk_ld(pk, PK_WEIGHT) * pk_ld3(pk, PK_SURFACE));
         // ---- secondary rays (world.rs:78-86, :113-148); once per light in the reference (Q4) ----
-        bool want_reflect = m_reflective != 0.f, want_refract = m_transparency != 0.f;
+        const RtMaterial& m = sc.materials[mat_id];
+        bool want_reflect = m.reflective != 0.f, want_refract = m.transparency != 0.f;
         if (remaining == 0 || sc.n_lights == 0 || (!want_reflect && !want_refract)) {
           st = ST_NEXT_RAY;
         } else if (want_refract && !(sc.props & RT_SCENE_RI_ALL_ONE)) {
-          tray = sray;
+          tray = Ray{pk_ld3(pk, PK_SRAY_O), pk_ld3(pk, PK_SRAY_D)};
           job = JOB_COLLECT;
           st = ST_TRACE;
         } else {
@@ -1321,6 +1475,12 @@ __device__ inline V3 color_at(const Scene& sc, const RenderParams& rp, Ray prima
           st = ST_SECONDARY;
         }
       } else if (st == ST_SECONDARY) {
+        const RtMaterial& m = sc.materials[mat_id];
+        const float m_reflective = m.reflective, m_transparency = m.transparency;
+        const Ray sray{pk_ld3(pk, PK_SRAY_O), pk_ld3(pk, PK_SRAY_D)};
+        const float weight = pk_ld(pk, PK_WEIGHT);
+        const V3 eyev = -sray.d;
+        const V3 point = sray.o + hit_t * sray.d;
         bool want_reflect = m_reflective != 0.f, want_refract = m_transparency != 0.f;
         float reflectance = 1.f, transmittance = 1.f;
         if (m_reflective > 0.f && m_transparency > 0.f) {  // Computations::schlick (intersections.rs:177-192)
@@ -1355,6 +1515,7 @@ __device__ inline V3 color_at(const Scene& sc, const RenderParams& rp, Ray prima
             V3 direction = (n_ratio * cos_i - cos_t) * normalv - n_ratio * eyev;
             float w = weight * nl * m_transparency * transmittance;
             if (sp < RT_MAX_RAY_STACK) {
+              const V3 under_point = point - 1e-4f * normalv;
               stack[sp++] = PendingRay{Ray{under_point, direction}, w, remaining - 1u, path * 2u + 1u};
               cn.refract++;
             } else {
@@ -1365,7 +1526,8 @@ __device__ inline V3 color_at(const Scene& sc, const RenderParams& rp, Ray prima
         if (want_reflect) {  // reflected_color (world.rs:113-125)
           float w = weight * nl * m_reflective * reflectance;
           if (sp < RT_MAX_RAY_STACK) {
-            stack[sp++] = PendingRay{Ray{over_point, reflectv}, w, remaining - 1u, path * 2u};
+            const V3 over_point = point + 1e-4f * normalv;
+            stack[sp++] = PendingRay{Ray{over_point, reflect(sray.d, normalv)}, w, remaining - 1u, path * 2u};
             cn.reflect++;
           } else {
             cn.overflow++;
@@ -1375,11 +1537,12 @@ __device__ inline V3 color_at(const Scene& sc, const RenderParams& rp, Ray prima
       } else {  // ST_NEXT_RAY
         if (sp > 0) {
           PendingRay pr = stack[--sp];
-          sray = pr.ray;
-          weight = pr.weight;
+          pk_st3(pk, PK_SRAY_O, pr.ray.o);
+          pk_st3(pk, PK_SRAY_D, pr.ray.d);
+          pk_st(pk, PK_WEIGHT, pr.weight);
           remaining = pr.remaining;
           path = pr.path;
-          tray = sray;
+          tray = pr.ray;
           job = JOB_SHADE;
           st = ST_TRACE;
         } else {
@@ -1387,8 +1550,12 @@ __device__ inline V3 color_at(const Scene& sc, const RenderParams& rp, Ray prima
         }
       }
     }
+    if (st == ST_DONE) {
+      const uint32_t work = COUNT ? cn.node_visits + cn.aux_tests + cn.tri_tests + cn.shape_tests - work_start : 0u;
+      src.finish(item, pk_ld3(pk, PK_RESULT), primary_hit, work, cn);
+      st = ST_IDLE;
+    }
   }
-  return result;
 }
 
 // ---------------------------------------------------------------------------------------

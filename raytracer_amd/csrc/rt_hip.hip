@@ -5,6 +5,7 @@
 // No FMA contraction and correctly rounded / and sqrt are REQUIRED for parity.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -19,6 +20,9 @@ using namespace rtd;
 namespace {
 
 #define RT_N_COUNTERS 16
+#ifndef RT_BLOCKS_PER_CU
+#define RT_BLOCKS_PER_CU 4  // 256-thread blocks resident per CU at four waves per SIMD
+#endif
 
 struct PartInfo {
   uint32_t tile_h, n_parts, part, rows;  // rows = number of local rows
@@ -35,6 +39,12 @@ __device__ __forceinline__ void flush_counters(const Counters& cn, unsigned long
   uint32_t w0 = wave_sum(cn.node_visits), w1 = wave_sum(cn.tri_tests), w2 = wave_sum(cn.shape_tests),
            w3 = wave_sum(cn.shaded), w4 = wave_sum(cn.xforms), w5 = wave_sum(cn.aux_tests);
   if ((threadIdx.x & 63) == 0) {
+#ifdef RT_PHASE_TIMERS
+    atomicAdd(g + 11, (unsigned long long)cn.t_world);
+    atomicAdd(g + 12, (unsigned long long)cn.t_aux);
+    atomicAdd(g + 13, (unsigned long long)cn.t_shapes);
+    atomicAdd(g + 10, (unsigned long long)cn.t_load);  // slot of aux_tests: meaningful in non-COUNT runs only
+#endif
     if (w0) atomicAdd(g + 5, (unsigned long long)w0);
     if (w1) atomicAdd(g + 6, (unsigned long long)w1);
     if (w2) atomicAdd(g + 7, (unsigned long long)w2);
@@ -49,22 +59,100 @@ __device__ __forceinline__ void flush_counters(const Counters& cn, unsigned long
   }
 }
 
-// Camera::render (camera.rs:66-84): one lane per pixel, one wave per 8x8 pixel tile, four waves
-// per 16x16 block.  Rows are the interleaved scanline tiles of this part.
-// Two kernel families share the pixel body:
-//   k_render_jobs    job-loop integrator (rt_device.h color_at).  Register budget capped at 128 VGPRs so four
-//                    waves share a SIMD: the traversal is a chain of dependent loads and at the compiler's natural
-//                    ~200 VGPRs (two waves) the SIMDs sat idle more than half the time (profiles/README.md).
-//   k_render_direct  direct integrator (color_at_direct) for group-less worlds whose cost is the shadow-sample
-//                    loop of an area light.
+// Camera::render (camera.rs:66-84).  Rows are the interleaved scanline tiles of this part.
+// Two kernel families:
+//   k_render_jobs    job-loop integrator (rt_device.h integrate) on persistent waves: pixels are work items in 8x8
+//                    tile order, drawn from a queue as lanes go idle.  Register budget capped at 128 VGPRs so four
+//                    waves share a SIMD (profiles/README.md).
+//   k_render_direct  direct integrator (color_at_direct), one lane per pixel, one wave per 8x8 tile, for group-less
+//                    worlds whose cost is the shadow-sample loop of an area light.
 #ifndef RT_WAVES_PER_EU
 #define RT_WAVES_PER_EU 4
 #endif
-template <bool COUNT, bool SIMPLE>
-__device__ __forceinline__ void render_pixel(const Scene& sc, const RtCamera& cam, const RenderParams& rp,
-                                             const PartInfo& part, float* __restrict__ out, uint8_t* __restrict__ mask,
-                                             int32_t* __restrict__ oid, float* __restrict__ ht,
-                                             unsigned long long* counters) {
+#define RT_QUEUE_SLOT 15  // d_counters slot used as the work queue of the persistent kernels
+
+__device__ __forceinline__ Ray ray_for_pixel(const RtCamera& cam, uint32_t px, uint32_t py) {  // camera.rs:45-64
+  float xoffset = ((float)px + 0.5f) * cam.pixel_size;
+  float yoffset = ((float)py + 0.5f) * cam.pixel_size;
+  float world_x = cam.half_width - xoffset;
+  float world_y = cam.half_height - yoffset;
+  V3 pixel = xf_point(cam.inv_transform, v3(world_x, world_y, -1.f));
+  V3 origin = xf_point(cam.inv_transform, v3(0.f, 0.f, 0.f));
+  return Ray{origin, normalize(pixel - origin)};
+}
+struct PixelOut {
+  float* __restrict__ out;
+  uint8_t* __restrict__ mask;
+  int32_t* __restrict__ oid;
+  float* __restrict__ ht;
+};
+template <bool COUNT>
+__device__ __forceinline__ void write_pixel(const Scene& sc, const PixelOut& o, size_t idx, V3 col, const Hit& ph, float work,
+                                            float work_shadow, float work_collect) {
+  o.out[3 * idx + 0] = col.x;
+  o.out[3 * idx + 1] = col.y;
+  o.out[3 * idx + 2] = col.z;
+  if (o.mask) o.mask[idx] = ph.shape >= 0 ? 1 : 0;
+  if (o.oid) o.oid[idx] = ph.shape;
+  if (o.ht) {
+    if (COUNT && (sc.flags & RT_RENDER_WORK_MAP))  // diagnostics: this pixel's traversal work instead of hit t
+      o.ht[idx] = (sc.flags & 0x10u) ? work_shadow : (sc.flags & 0x20u) ? work_collect : work;
+    else
+      o.ht[idx] = ph.shape >= 0 ? ph.t : __builtin_nanf("");
+  }
+}
+// work items of a frame: pixel `item & 63` of 8x8 tile `item >> 6`, tiles in row-major order
+template <bool COUNT>
+struct PixelSource {
+  const Scene* sc;
+  RtCamera cam;
+  PartInfo part;
+  PixelOut o;
+  uint32_t tiles_x, tiles_y;
+  __device__ uint32_t total() const { return tiles_x * tiles_y * 64u; }
+  __device__ void locate(uint32_t item, uint32_t& px, uint32_t& ly) const {
+    uint32_t tile = item >> 6, w = item & 63u;
+    px = (tile % tiles_x) * 8u + (w & 7u);
+    ly = (tile / tiles_x) * 8u + (w >> 3);
+  }
+  __device__ bool start(uint32_t item, Ray& r, uint32_t& pixel) const {
+    uint32_t px, ly;
+    locate(item, px, ly);
+    if (px >= cam.hsize || ly >= part.rows) return false;
+    const uint32_t py = (ly / part.tile_h) * (part.n_parts * part.tile_h) + part.part * part.tile_h + (ly % part.tile_h);
+    r = ray_for_pixel(cam, px, py);
+    pixel = py * cam.hsize + px;
+    return true;
+  }
+  __device__ void finish(uint32_t item, V3 col, const Hit& ph, uint32_t work, Counters& cn) const {
+    uint32_t px, ly;
+    locate(item, px, ly);
+    float ws = 0.f, wc = 0.f;
+    if (COUNT) {  // per-pixel shares for the work map
+      ws = (float)cn.work_shadow, wc = (float)cn.work_collect;
+      cn.work_shadow = 0;
+      cn.work_collect = 0;
+    }
+    write_pixel<COUNT>(*sc, o, (size_t)ly * cam.hsize + px, col, ph, (float)work, ws, wc);
+  }
+};
+template <bool COUNT>
+__global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAVES_PER_EU, RT_WAVES_PER_EU)))
+void k_render_jobs(Scene sc, RtCamera cam, RenderParams rp, PartInfo part, PixelOut o, unsigned long long* counters) {
+#ifdef RT_PHASE_TIMERS
+  const uint64_t t_pixel0 = __builtin_readcyclecounter();
+#endif
+  PixelSource<COUNT> src{&sc, cam, part, o, (cam.hsize + 7u) / 8u, (part.rows + 7u) / 8u};
+  Counters cn = {};
+  integrate<COUNT>(sc, rp, src, sc.recursion_limit, counters + RT_QUEUE_SLOT, cn);
+#ifdef RT_PHASE_TIMERS
+  if ((threadIdx.x & 63) == 0) atomicAdd(counters + 14, (unsigned long long)(__builtin_readcyclecounter() - t_pixel0));
+#endif
+  flush_counters(cn, counters);
+}
+template <bool COUNT>
+__global__ __launch_bounds__(RT_BLOCK)
+void k_render_direct(Scene sc, RtCamera cam, RenderParams rp, PartInfo part, PixelOut o, unsigned long long* counters) {
   const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
 #if RT_BLOCK == 256
   const uint32_t px = blockIdx.x * 16u + (wave & 1u) * 8u + (lane & 7u);
@@ -74,79 +162,72 @@ __device__ __forceinline__ void render_pixel(const Scene& sc, const RtCamera& ca
   const uint32_t ly = blockIdx.y * 8u + (lane >> 3);
   (void)wave;
 #endif
-  Counters cn = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  Counters cn = {};
   if (px < cam.hsize && ly < part.rows) {
     const uint32_t py = (ly / part.tile_h) * (part.n_parts * part.tile_h) + part.part * part.tile_h + (ly % part.tile_h);
-    // Camera::ray_for_pixel (camera.rs:45-64)
-    float xoffset = ((float)px + 0.5f) * cam.pixel_size;
-    float yoffset = ((float)py + 0.5f) * cam.pixel_size;
-    float world_x = cam.half_width - xoffset;
-    float world_y = cam.half_height - yoffset;
-    V3 pixel = xf_point(cam.inv_transform, v3(world_x, world_y, -1.f));
-    V3 origin = xf_point(cam.inv_transform, v3(0.f, 0.f, 0.f));
-    V3 direction = normalize(pixel - origin);
     cn.primary = 1;
     Hit ph;
-    V3 col = SIMPLE ? color_at_direct<COUNT>(sc, rp, Ray{origin, direction}, sc.recursion_limit, py * cam.hsize + px, cn, &ph)
-                    : color_at<COUNT>(sc, rp, Ray{origin, direction}, sc.recursion_limit, py * cam.hsize + px, cn, &ph);
-    size_t idx = (size_t)ly * cam.hsize + px;
-    out[3 * idx + 0] = col.x;
-    out[3 * idx + 1] = col.y;
-    out[3 * idx + 2] = col.z;
-    if (mask) mask[idx] = ph.shape >= 0 ? 1 : 0;
-    if (oid) oid[idx] = ph.shape;
-    if (ht) {
-      if (COUNT && (sc.flags & RT_RENDER_WORK_MAP))  // diagnostics: this pixel's traversal work instead of hit t
-        ht[idx] = (sc.flags & 0x10u) ? (float)cn.work_shadow
-                  : (sc.flags & 0x20u) ? (float)cn.work_collect
-                                       : (float)(cn.node_visits + cn.aux_tests + cn.tri_tests + cn.shape_tests);
-      else
-        ht[idx] = ph.shape >= 0 ? ph.t : __builtin_nanf("");
-    }
+    V3 col = color_at_direct<COUNT>(sc, rp, ray_for_pixel(cam, px, py), sc.recursion_limit, py * cam.hsize + px, cn, &ph);
+    write_pixel<COUNT>(sc, o, (size_t)ly * cam.hsize + px, col, ph,
+                       (float)(cn.node_visits + cn.aux_tests + cn.tri_tests + cn.shape_tests), (float)cn.work_shadow,
+                       (float)cn.work_collect);
   }
   flush_counters(cn, counters);
 }
-template <bool COUNT>
-__global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAVES_PER_EU, RT_WAVES_PER_EU)))
-void k_render_jobs(Scene sc, RtCamera cam, RenderParams rp, PartInfo part, float* __restrict__ out,
-                   uint8_t* __restrict__ mask, int32_t* __restrict__ oid, float* __restrict__ ht,
-                   unsigned long long* counters) {
-  render_pixel<COUNT, false>(sc, cam, rp, part, out, mask, oid, ht, counters);
-}
-template <bool COUNT>
-__global__ __launch_bounds__(RT_BLOCK)
-void k_render_direct(Scene sc, RtCamera cam, RenderParams rp, PartInfo part, float* __restrict__ out,
-                     uint8_t* __restrict__ mask, int32_t* __restrict__ oid, float* __restrict__ ht,
-                     unsigned long long* counters) {
-  render_pixel<COUNT, true>(sc, cam, rp, part, out, mask, oid, ht, counters);
-}
 
 // World::color_at for caller-supplied rays (world.rs:91-99).
-template <bool COUNT, bool SIMPLE>
-__global__ __launch_bounds__(RT_BLOCK) void k_color_at(Scene sc, RenderParams rp, const float* __restrict__ origins,
-                                                  const float* __restrict__ directions, uint32_t n,
-                                                  uint32_t remaining, float* __restrict__ out,
-                                                  float* __restrict__ hit_t, int32_t* __restrict__ hit_id,
-                                                  float* __restrict__ hit_uv, unsigned long long* counters) {
+struct RayOut {
+  const float* __restrict__ origins;
+  const float* __restrict__ directions;
+  uint32_t n;
+  float* __restrict__ out;
+  float* __restrict__ hit_t;
+  int32_t* __restrict__ hit_id;
+  float* __restrict__ hit_uv;
+};
+__device__ __forceinline__ void write_ray(const RayOut& o, uint32_t i, V3 col, const Hit& ph) {
+  if (o.out) {
+    o.out[3 * i] = col.x;
+    o.out[3 * i + 1] = col.y;
+    o.out[3 * i + 2] = col.z;
+  }
+  if (o.hit_t) o.hit_t[i] = ph.shape >= 0 ? ph.t : __builtin_nanf("");
+  if (o.hit_id) o.hit_id[i] = ph.shape;
+  if (o.hit_uv) {
+    o.hit_uv[2 * i] = ph.shape >= 0 && ph.u == ph.u ? ph.u : 0.f;
+    o.hit_uv[2 * i + 1] = ph.shape >= 0 && ph.v == ph.v ? ph.v : 0.f;
+  }
+}
+struct RaySource {
+  RayOut o;
+  __device__ uint32_t total() const { return o.n; }
+  __device__ bool start(uint32_t i, Ray& r, uint32_t& pixel) const {
+    r = Ray{v3(o.origins[3 * i], o.origins[3 * i + 1], o.origins[3 * i + 2]),
+            v3(o.directions[3 * i], o.directions[3 * i + 1], o.directions[3 * i + 2])};
+    pixel = i;
+    return true;
+  }
+  __device__ void finish(uint32_t i, V3 col, const Hit& ph, uint32_t, Counters&) const { write_ray(o, i, col, ph); }
+};
+template <bool COUNT>
+__global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAVES_PER_EU, RT_WAVES_PER_EU)))
+void k_color_at_jobs(Scene sc, RenderParams rp, RayOut o, uint32_t remaining, unsigned long long* counters) {
+  RaySource src{o};
+  Counters cn = {};
+  integrate<COUNT>(sc, rp, src, remaining, counters + RT_QUEUE_SLOT, cn);
+  flush_counters(cn, counters);
+}
+__global__ __launch_bounds__(RT_BLOCK) void k_color_at_direct(Scene sc, RenderParams rp, RayOut o, uint32_t remaining,
+                                                             unsigned long long* counters) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  Counters cn = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  if (i < n) {
-    Ray r{v3(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]),
-          v3(directions[3 * i], directions[3 * i + 1], directions[3 * i + 2])};
+  Counters cn = {};
+  if (i < o.n) {
+    Ray r{v3(o.origins[3 * i], o.origins[3 * i + 1], o.origins[3 * i + 2]),
+          v3(o.directions[3 * i], o.directions[3 * i + 1], o.directions[3 * i + 2])};
     cn.primary = 1;
     Hit ph;
-    V3 col = SIMPLE ? color_at_direct<COUNT>(sc, rp, r, remaining, i, cn, &ph) : color_at<COUNT>(sc, rp, r, remaining, i, cn, &ph);
-    if (out) {
-      out[3 * i] = col.x;
-      out[3 * i + 1] = col.y;
-      out[3 * i + 2] = col.z;
-    }
-    if (hit_t) hit_t[i] = ph.shape >= 0 ? ph.t : __builtin_nanf("");
-    if (hit_id) hit_id[i] = ph.shape;
-    if (hit_uv) {
-      hit_uv[2 * i] = ph.shape >= 0 && ph.u == ph.u ? ph.u : 0.f;
-      hit_uv[2 * i + 1] = ph.shape >= 0 && ph.v == ph.v ? ph.v : 0.f;
-    }
+    V3 col = color_at_direct<false>(sc, rp, r, remaining, i, cn, &ph);
+    write_ray(o, i, col, ph);
   }
   flush_counters(cn, counters);
 }
@@ -161,6 +242,7 @@ struct RtContext {
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   unsigned long long* d_counters = nullptr;
+  uint32_t n_cus = 256;
   std::string error;
 };
 struct RtDeviceScene {
@@ -312,6 +394,9 @@ int read_stats(RtContext* ctx, hipStream_t stream, RtStats* stats, double total_
   stats->shaded_hits = h[8];
   stats->node_xforms = h[9];
   stats->aux_tests = h[10];
+#ifdef RT_PHASE_TIMERS
+  fprintf(stderr, "phase clocks (wave sums): pixel %llu  world_intersect %llu  aux %llu  shapes %llu  walk iterations %llu  node load %llu\n", h[14], h[11], h[12], h[13], h[15], h[10]);
+#endif
   stats->kernel_ms = ms;
   stats->total_ms = total_ms;
   return RT_OK;
@@ -335,6 +420,12 @@ int rt_context_create(int device, RtContext** out) {
   };
   hipError_t e;
   if ((e = hipSetDevice(device)) != hipSuccess) return bail(e, "hipSetDevice");
+  {
+    int cus = 0;
+    if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device)) != hipSuccess)
+      return bail(e, "hipDeviceGetAttribute");
+    c->n_cus = cus > 0 ? (uint32_t)cus : 256u;
+  }
   if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
   if ((e = hipEventCreate(&c->ev0)) != hipSuccess) return bail(e, "hipEventCreate");
   if ((e = hipEventCreate(&c->ev1)) != hipSuccess) return bail(e, "hipEventCreate");
@@ -486,16 +577,25 @@ int rt_render_device(RtContext* ctx, const RtDeviceScene* ds, const RtCamera* ca
   RenderParams rp = make_params(opts);
   HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, RT_N_COUNTERS * sizeof(unsigned long long), stream));
   if (part.rows > 0) {
-    const uint32_t tile = RT_BLOCK == 256 ? 16u : 8u;
-    dim3 grid((cam->hsize + tile - 1) / tile, (part.rows + tile - 1) / tile);
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
     // both integrators give the same bits; the direct one wins where an area light's sample loop dominates
     const bool direct = sc.n_nodes == 0 && (sc.props & RT_SCENE_AREA_LIGHT);
-    auto kern = (sc.flags & RT_RENDER_COUNT_WORK) ? (direct ? k_render_direct<true> : k_render_jobs<true>)
-                                                  : (direct ? k_render_direct<false> : k_render_jobs<false>);
-    hipLaunchKernelGGL(kern, grid, dim3(RT_BLOCK), 0, stream, sc, *cam, rp, part, d_out_rgb,
-                       d_aux ? d_aux->hit_mask : nullptr, d_aux ? d_aux->object_id : nullptr,
-                       d_aux ? d_aux->hit_t : nullptr, ctx->d_counters);
+    const bool count = (sc.flags & RT_RENDER_COUNT_WORK) != 0;
+    PixelOut po{d_out_rgb, d_aux ? d_aux->hit_mask : nullptr, d_aux ? d_aux->object_id : nullptr,
+                d_aux ? d_aux->hit_t : nullptr};
+    if (direct) {
+      const uint32_t tile = RT_BLOCK == 256 ? 16u : 8u;
+      dim3 grid((cam->hsize + tile - 1) / tile, (part.rows + tile - 1) / tile);
+      hipLaunchKernelGGL(count ? k_render_direct<true> : k_render_direct<false>, grid, dim3(RT_BLOCK), 0, stream, sc, *cam,
+                         rp, part, po, ctx->d_counters);
+    } else {
+      // persistent waves: enough blocks to fill the device at four waves per SIMD, never more than the work
+      const uint64_t items = (uint64_t)((cam->hsize + 7u) / 8u) * ((part.rows + 7u) / 8u) * 64u;
+      if (items >= 0xFFFFFFFFull) return fail(ctx, RT_E_ABI, "image too large");
+      const uint32_t blocks = (uint32_t)std::min<uint64_t>((items + RT_BLOCK - 1) / RT_BLOCK, (uint64_t)ctx->n_cus * RT_BLOCKS_PER_CU);
+      hipLaunchKernelGGL(count ? k_render_jobs<true> : k_render_jobs<false>, dim3(blocks), dim3(RT_BLOCK), 0, stream, sc,
+                         *cam, rp, part, po, ctx->d_counters);
+    }
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev1, stream));
   } else {
@@ -604,10 +704,15 @@ int rt_color_at(RtContext* ctx, const RtDeviceScene* ds, const RtRenderOptions* 
   sc.flags = opts ? opts->flags : 0;
   RenderParams rp = make_params(opts);
   TRY_CLEAN(hipEventRecord(ctx->ev0, ctx->stream));
-  auto ckern = sc.n_nodes == 0 ? k_color_at<false, true>
-               : (sc.flags & RT_RENDER_COUNT_WORK) ? k_color_at<true, false> : k_color_at<false, false>;
-  hipLaunchKernelGGL(ckern, dim3((n + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, ctx->stream, sc, rp, d_o, d_d, n, remaining,
-                     d_rgb, d_t, d_id, d_uv, ctx->d_counters);
+  RayOut ro{d_o, d_d, n, d_rgb, d_t, d_id, d_uv};
+  if (sc.n_nodes == 0) {
+    hipLaunchKernelGGL(k_color_at_direct, dim3((n + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, ctx->stream, sc, rp, ro,
+                       remaining, ctx->d_counters);
+  } else {
+    const uint32_t blocks = std::min<uint32_t>((n + RT_BLOCK - 1) / RT_BLOCK, ctx->n_cus * RT_BLOCKS_PER_CU);
+    hipLaunchKernelGGL((sc.flags & RT_RENDER_COUNT_WORK) ? k_color_at_jobs<true> : k_color_at_jobs<false>, dim3(blocks),
+                       dim3(RT_BLOCK), 0, ctx->stream, sc, rp, ro, remaining, ctx->d_counters);
+  }
   TRY_CLEAN(hipGetLastError());
   TRY_CLEAN(hipEventRecord(ctx->ev1, ctx->stream));
   TRY_CLEAN(hipStreamSynchronize(ctx->stream));
