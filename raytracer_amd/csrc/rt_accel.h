@@ -145,6 +145,15 @@ struct TreeBuilder {
     return true;
   }
 
+  // levels a median-split tree needs below a node that holds n triangles
+  static int levels_for(uint32_t n) {
+    int l = 0;
+    while (n > kLeafTris) {
+      n = (n + 1) / 2;
+      l++;
+    }
+    return l;
+  }
   // child reference for [b,e): (index, count) and its box
   void build(uint32_t b, uint32_t e, int depth, uint32_t* ref, uint32_t* count, float* lo, float* hi) {
     depth_seen = std::max(depth_seen, depth);
@@ -171,20 +180,83 @@ struct TreeBuilder {
       }
       return;
     }
-    // object-median split on the axis of largest centroid extent: balanced, depth = ceil(log2(n/leaf))
+    // Split: binned surface-area heuristic over the centroids (16 bins per axis); the object median on the axis of
+    // largest centroid extent when SAH finds nothing or when its split would leave a child too many triangles for
+    // the levels that remain (a median tree below depth d with n triangles needs `levels_for(n)` more levels, and the
+    // traversal stack is sized for kMaxDepth).
     float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (uint32_t i = b; i < e; i++)
       for (int a = 0; a < 3; a++) {
         clo[a] = std::min(clo[a], items[i].c[a]);
         chi[a] = std::max(chi[a], items[i].c[a]);
       }
-    int axis = 0;
-    for (int a = 1; a < 3; a++)
-      if (chi[a] - clo[a] > chi[axis] - clo[axis]) axis = a;
-    uint32_t mid = b + n / 2;
-    std::nth_element(items.begin() + b, items.begin() + mid, items.begin() + e, [axis](const Item& x, const Item& y) {
-      return x.c[axis] < y.c[axis] || (x.c[axis] == y.c[axis] && x.shape < y.shape);
-    });
+    uint32_t mid = 0;
+    {
+      constexpr int kBins = 16;
+      double best = INFINITY;
+      int best_axis = -1, best_split = 0;
+      for (int axis = 0; axis < 3; axis++) {
+        const float ext = chi[axis] - clo[axis];
+        if (!(ext > 0.f)) continue;
+        const float scale = kBins / ext;
+        uint32_t cnt[kBins] = {0};
+        float blo_[kBins][3], bhi_[kBins][3];
+        for (int k = 0; k < kBins; k++)
+          for (int a = 0; a < 3; a++) blo_[k][a] = INFINITY, bhi_[k][a] = -INFINITY;
+        for (uint32_t i = b; i < e; i++) {
+          int k = std::min(kBins - 1, std::max(0, (int)((items[i].c[axis] - clo[axis]) * scale)));
+          cnt[k]++;
+          for (int a = 0; a < 3; a++) {
+            blo_[k][a] = std::min(blo_[k][a], items[i].lo[a]);
+            bhi_[k][a] = std::max(bhi_[k][a], items[i].hi[a]);
+          }
+        }
+        // sweep from the right, then from the left
+        double ra[kBins];
+        uint32_t rn[kBins];
+        float l3[3] = {INFINITY, INFINITY, INFINITY}, h3[3] = {-INFINITY, -INFINITY, -INFINITY};
+        uint32_t acc = 0;
+        auto area = [](const float* l, const float* h) {
+          double dx = (double)h[0] - l[0], dy = (double)h[1] - l[1], dz = (double)h[2] - l[2];
+          return dx * dy + dy * dz + dz * dx;
+        };
+        for (int k = kBins - 1; k > 0; k--) {
+          for (int a = 0; a < 3; a++) l3[a] = std::min(l3[a], blo_[k][a]), h3[a] = std::max(h3[a], bhi_[k][a]);
+          acc += cnt[k];
+          ra[k] = acc ? area(l3, h3) : 0.0;
+          rn[k] = acc;
+        }
+        for (int a = 0; a < 3; a++) l3[a] = INFINITY, h3[a] = -INFINITY;
+        acc = 0;
+        for (int k = 0; k + 1 < kBins; k++) {  // split after bin k
+          for (int a = 0; a < 3; a++) l3[a] = std::min(l3[a], blo_[k][a]), h3[a] = std::max(h3[a], bhi_[k][a]);
+          acc += cnt[k];
+          if (acc == 0 || rn[k + 1] == 0) continue;
+          if (depth + 1 + levels_for(acc) > kMaxDepth || depth + 1 + levels_for(rn[k + 1]) > kMaxDepth) continue;
+          double cost = area(l3, h3) * acc + ra[k + 1] * rn[k + 1];
+          if (cost < best) best = cost, best_axis = axis, best_split = k;
+        }
+      }
+      if (best_axis >= 0) {
+        const int axis = best_axis;
+        const float scale = kBins / (chi[axis] - clo[axis]);
+        const float lo_c = clo[axis];
+        const int split = best_split;
+        auto it = std::stable_partition(items.begin() + b, items.begin() + e, [=](const Item& x) {
+          return std::min(kBins - 1, std::max(0, (int)((x.c[axis] - lo_c) * scale))) <= split;
+        });
+        mid = (uint32_t)(it - items.begin());
+      }
+    }
+    if (mid <= b || mid >= e) {
+      int axis = 0;
+      for (int a = 1; a < 3; a++)
+        if (chi[a] - clo[a] > chi[axis] - clo[axis]) axis = a;
+      mid = b + n / 2;
+      std::nth_element(items.begin() + b, items.begin() + mid, items.begin() + e, [axis](const Item& x, const Item& y) {
+        return x.c[axis] < y.c[axis] || (x.c[axis] == y.c[axis] && x.shape < y.shape);
+      });
+    }
     uint32_t me = (uint32_t)nodes.size();
     nodes.emplace_back();
     *ref = me;

@@ -19,4 +19,4 @@ for px, py in pix:
         rc = lib.rt_color_at(ctx, ds, C.byref(opts), o.ctypes.data_as(P), d.ctypes.data_as(P), 1, rem,
                              rgb.ctypes.data_as(P), t.ctypes.data_as(P), ids.ctypes.data_as(P), uv.ctypes.data_as(P), C.byref(st))
         print((px, py), "rem", rem, "rc", rc, "o", o, "d", d, "rgb", rgb, "t", t[0], "id", ids[0],
-              {f: getattr(st, f) for f, _ in st._fields_ if f not in ("kernel_ms", "total_ms")}, flush=True)
+              {f: getattr(st, f) for f, _ in st._fields_ }, flush=True)
