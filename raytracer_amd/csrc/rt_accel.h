@@ -46,7 +46,10 @@ namespace rtaccel {
 
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr uint32_t kMinTris = 12;    // subtrees with fewer triangles keep the reference walk
-constexpr uint32_t kLeafTris = 4;    // max triangles per leaf
+#ifndef RT_LEAF_TRIS
+#define RT_LEAF_TRIS 7
+#endif
+constexpr uint32_t kLeafTris = RT_LEAF_TRIS;    // max triangles per leaf
 constexpr int kMaxDepth = 22;        // device stack holds kMaxDepth + 2 entries
 constexpr float kPadRel = 0.01f;     // static box padding relative to the triangle's largest extent
 constexpr float kPadAbs = 4e-6f;     // ... plus this times the largest |coordinate|

@@ -1201,16 +1201,19 @@ __device__ __forceinline__ void pk_st3(const Park& pk, int k, V3 x) {
   pk_st(pk, k + 2, x.z);
 }
 
-// Persistent waves: a lane that finishes its pixel (or ray) does not wait for the slowest lane of its wave; it goes
-// idle, and once RT_REFILL_MIN lanes of the wave are idle they take the next items of the work queue together (one
-// atomic per refill; consecutive items are neighbouring pixels of an 8x8 tile).  Per-pixel work varies by three orders
-// of magnitude in the dragons scene, so this is what keeps lanes busy and what removes the long tail of a frame.
+// Persistent waves with a work queue: a wave draws its next items itself (one atomic per refill) instead of being
+// born for one tile, so heavy tiles do not leave CUs idle at the end of a frame and the grid is sized to the device,
+// not to the image.  Lanes that finish go idle; once RT_REFILL_MIN lanes of the wave are idle they take the next items
+// together.  Measured on dragons/cover at 4K: refilling partly idle waves (threshold 1..32) keeps more lanes busy but
+// mixes pixels of different tiles in one wave, and the loss of coherence in the traversal costs more than the idle
+// lanes did (4.8 / 4.7 / 4.5 / 4.3 ms for 1 / 8 / 32 / 64), so the default is 64: a wave takes a whole 8x8 tile
+// (64 consecutive items) when all its lanes are done.
 // `Source` supplies the work: total(), start(item, ray, id) -> false if the item is outside the image, and
 // finish(item, colour, primary hit, work).  `queue` is a zeroed counter in device memory.
 // Every wave leaves the loop: each refill advances the queue, and a wave whose lanes are all idle either refills
 // or, once the queue has run past total(), breaks.
 #ifndef RT_REFILL_MIN
-#define RT_REFILL_MIN 16
+#define RT_REFILL_MIN 64
 #endif
 enum { ST_IDLE = 100 };
 template <bool COUNT, class Source>

@@ -156,7 +156,7 @@ def test_aux_bvh_is_well_formed(obj_files):
                 if cnt == 0:
                     stack.append((ref, depth + 1, mn, mx))
                     continue
-                assert 1 <= cnt <= 4
+                assert 1 <= cnt <= 7
                 for t in at[ref:ref + cnt]:
                     si, owner = int(t["shape"]), int(t["owner"])
                     covered[si] += 1
