@@ -372,6 +372,7 @@ struct Sink {
   float tcap;     // closest: upper bound of interest (inf, or the distance to the light)
   int mode;
   bool found;     // any-shadow: an occluder has been found, the traversal may stop
+  float lim;      // nothing beyond this t can matter any more (kept up to date by add)
   __device__ __forceinline__ void init(int mode_) {
     t = __builtin_inff();
     u = v = 0.f;
@@ -386,6 +387,11 @@ struct Sink {
     tcap = __builtin_inff();
     mode = mode_;
     found = false;
+    lim = __builtin_inff();
+  }
+  __device__ __forceinline__ void set_cap(float cap) {  // closest: nothing at or beyond cap can matter (shadow rays)
+    tcap = cap;
+    lim = __builtin_fminf(t, cap);
   }
   __device__ __forceinline__ void init_closest() { init(SINK_CLOSEST); }
   __device__ __forceinline__ void init_collect(float* ts_, uint32_t* ss_, float tlimit_) {
@@ -393,6 +399,7 @@ struct Sink {
     ts = ts_;
     ss = ss_;
     tlimit = tlimit_;
+    lim = tlimit_;
   }
   // World::is_shadowed (world.rs:101-111) looks at the closest hit h* only: shadowed <=> t* < distance and
   // h*.shape.shadow().  With F = closest hit among shadow-less shapes, that is equivalent to: some hit x on a
@@ -403,6 +410,7 @@ struct Sink {
     tlimit = distance;
     tF = tF_;
     sF = sF_;
+    lim = __builtin_fminf(distance, tF_);
   }
   // does this traversal look at a shape with these flags at all?
   __device__ __forceinline__ bool takes(uint32_t kind_flags) const {
@@ -428,7 +436,9 @@ struct Sink {
       }
     } else if (mode == SINK_ANY_SHADOW) {
       found = true;
+      lim = -__builtin_inff();
     } else {
+      lim = __builtin_fminf(tt, tcap);
       t = tt;
       shape = (int)s;
       u = uu;
@@ -436,11 +446,7 @@ struct Sink {
     }
   }
   // nothing beyond this t can matter any more
-  __device__ __forceinline__ float limit() const {
-    if (mode == SINK_COLLECT) return tlimit;
-    if (mode == SINK_ANY_SHADOW) return found ? -__builtin_inff() : __builtin_fminf(tlimit, tF);
-    return shape < 0 ? tcap : __builtin_fminf(t, tcap);  // tcap: nothing at or beyond it can matter (shadow rays)
-  }
+  __device__ __forceinline__ float limit() const { return lim; }
   __device__ __forceinline__ bool wants_negative() const { return mode == SINK_COLLECT; }
   __device__ __forceinline__ bool done() const { return mode == SINK_ANY_SHADOW && found; }
 };
@@ -648,6 +654,7 @@ __device__ inline bool aux_intersect(const Scene& sc, uint32_t root_node, uint32
   // nodes without a cone bound, and the walk through them is still no longer than the reference's.
   if (!(padk * kmax < __builtin_inff())) return false;
   const V3 dn = cur.d / dm;
+  const float inv_dm = __builtin_amdgcn_rcpf(dm) * 1.000001f;  // t slack = pad / |d|, rounded up
   // the cone bound costs a fifth load and ~25 operations per node: only worth it when the worst-case pad is not
   // already small against the tree's triangles
   const bool use_cone = padk * kmax > RT_CONE_MIN_PAD * h1.x;
@@ -688,7 +695,7 @@ __device__ inline bool aux_intersect(const Scene& sc, uint32_t root_node, uint32
       }
 #endif
       const float pad = padk * kb;
-      const float tpad = pad / dm;
+      const float tpad = pad * inv_dm;
       const float lo = lo0 - tpad;
       float lim = sink.limit();
       float hi = (lim + 1e-5f * __builtin_fabsf(lim)) + tpad;
@@ -1294,7 +1301,7 @@ __device__ inline void integrate(const Scene& sc, const RenderParams& rp, const 
       sink.init_collect(xs_t, xs_s, hit_t);
     else if (job == JOB_SHADOW && (sc.props & RT_SCENE_HAS_NOSHADOW) && !(sc.props & RT_SCENE_SHADOW_TWO_PASS)) {
       sink.init_closest();  // small scene with shadow-less shapes: one closest-hit pass, capped at the light
-      sink.tcap = distance;
+      sink.set_cap(distance);
     } else if (job == JOB_SHADOW)
       sink.init_any_shadow(distance, shadow_tF, shadow_sF);
     else if (job == JOB_SHADOW_F)
@@ -1600,7 +1607,7 @@ __device__ __forceinline__ bool direct_is_shadowed(const Scene& sc, V3 light_pos
   Sink sink;
   if (sc.props & RT_SCENE_HAS_NOSHADOW) {
     sink.init_closest();
-    sink.tcap = distance;
+    sink.set_cap(distance);
     simple_intersect<COUNT>(sc, Ray{p, direction}, sink, cn);
     return sink.shape >= 0 && sink.t < distance && (sc.shapes[sink.shape].kind_flags & RT_SHAPE_SHADOW);
   }
