@@ -73,15 +73,23 @@ struct Counters {
   uint32_t work_shadow, work_collect;  // COUNT only: tests spent in shadow rays / n1-n2 collect passes
 #ifdef RT_PHASE_TIMERS
   uint32_t t_iters, t_load;
+  uint32_t u[8];  // lane / wave step counts: aux node, aux leaf, walk visit, walk shapes
   uint32_t t_world, t_aux, t_shapes;   // diagnostics build: wave clock spent in world_intersect / aux BVH / shape tests
 #endif
 };
 #ifdef RT_PHASE_TIMERS
 #define RT_T0(v) const uint64_t v = __builtin_readcyclecounter()
 #define RT_TACC(field, v) cn.field += (uint32_t)(__builtin_readcyclecounter() - v)
+// lane utilisation of a step: every active lane counts itself, the first active lane counts the wave
+#define RT_UTIL(k)                                                                                        \
+  do {                                                                                                    \
+    cn.u[2 * (k)]++;                                                                                      \
+    if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) cn.u[2 * (k) + 1]++; \
+  } while (0)
 #else
 #define RT_T0(v)
 #define RT_TACC(field, v)
+#define RT_UTIL(k)
 #endif
 
 struct Scene {
@@ -670,6 +678,7 @@ __device__ inline bool aux_intersect(const Scene& sc, uint32_t root_node, uint32
     if (cnt == 0u) {
       const float4* N = sc.aux_nodes + 5u * (size_t)idx;
       float4 n0 = N[0], n1 = N[1], n2 = N[2], n3 = N[3];
+      RT_UTIL(0);
       if (COUNT) cn.aux_tests += 2;
       float kb = kmax;
       float4 n4 = make_float4(0.f, 0.f, 0.f, -2.f);
@@ -717,6 +726,7 @@ __device__ inline bool aux_intersect(const Scene& sc, uint32_t root_node, uint32
       }
     } else {
       if (COUNT) cn.tri_tests += cnt;
+      RT_UTIL(1);
       const float4* T = sc.aux_tris + 3u * (size_t)idx;
       for (uint32_t k = 0; k < cnt; k++) {
         float4 a = T[3 * k], b = T[3 * k + 1], c = T[3 * k + 2];
@@ -814,6 +824,7 @@ __device__ RT_WI_INLINE void world_intersect(const Scene& sc, const Ray& ray, Si
           leave_at = q >= 0 ? sc.nodes[q].skip : 0xFFFFFFFFu;
         }
         if (COUNT) cn.node_visits++;
+        RT_UTIL(2);
         if (COUNT && xform) cn.xforms++;
         if (xform) {
           cur = xf_ray(sc, xform, cur);
@@ -852,7 +863,10 @@ __device__ RT_WI_INLINE void world_intersect(const Scene& sc, const Ray& ray, Si
         } else {
           if (COUNT && descend) cn.shape_tests += n_shapes;
           for (uint32_t k = 0; k < n_shapes; k++)
-            if (descend) shape_intersect(sc, first_shape + k, cur, sink);
+            if (descend) {
+              RT_UTIL(3);
+              shape_intersect(sc, first_shape + k, cur, sink);
+            }
         }
         RT_TACC(t_shapes, ts);
         if (my_i == i) my_i = descend ? i + 1u : skip;

@@ -19,7 +19,11 @@ using namespace rtd;
 
 namespace {
 
+#ifdef RT_PHASE_TIMERS
+#define RT_N_COUNTERS 32
+#else
 #define RT_N_COUNTERS 16
+#endif
 #ifndef RT_BLOCKS_PER_CU
 #define RT_BLOCKS_PER_CU 4  // 256-thread blocks resident per CU at four waves per SIMD
 #endif
@@ -38,6 +42,12 @@ __device__ __forceinline__ void flush_counters(const Counters& cn, unsigned long
            e = wave_sum(cn.overflow);
   uint32_t w0 = wave_sum(cn.node_visits), w1 = wave_sum(cn.tri_tests), w2 = wave_sum(cn.shape_tests),
            w3 = wave_sum(cn.shaded), w4 = wave_sum(cn.xforms), w5 = wave_sum(cn.aux_tests);
+#ifdef RT_PHASE_TIMERS
+  for (int k = 0; k < 8; k++) {
+    uint32_t v = wave_sum(cn.u[k]);
+    if ((threadIdx.x & 63) == 0) atomicAdd(g + 16 + k, (unsigned long long)v);
+  }
+#endif
   if ((threadIdx.x & 63) == 0) {
 #ifdef RT_PHASE_TIMERS
     atomicAdd(g + 11, (unsigned long long)cn.t_world);
@@ -395,6 +405,12 @@ int read_stats(RtContext* ctx, hipStream_t stream, RtStats* stats, double total_
   stats->node_xforms = h[9];
   stats->aux_tests = h[10];
 #ifdef RT_PHASE_TIMERS
+  {
+    const char* nm[4] = {"aux node", "aux leaf", "walk visit", "walk shape"};
+    for (int k = 0; k < 4; k++)
+      fprintf(stderr, "%s steps: lanes %llu waves %llu utilisation %.3f\n", nm[k], h[16 + 2 * k], h[17 + 2 * k],
+              h[17 + 2 * k] ? (double)h[16 + 2 * k] / (64.0 * h[17 + 2 * k]) : 0.0);
+  }
   fprintf(stderr, "phase clocks (wave sums): pixel %llu  world_intersect %llu  aux %llu  shapes %llu  walk iterations %llu  node load %llu\n", h[14], h[11], h[12], h[13], h[15], h[10]);
 #endif
   stats->kernel_ms = ms;
