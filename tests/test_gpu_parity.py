@@ -177,6 +177,28 @@ def test_parts_reassemble_at_4k(name, size):
         assert rays == st.primary + st.shadow + st.reflect + st.refract
 
 
+@pytest.mark.parametrize("size", [(1, 1), (7, 3), (65, 9), (130, 67)])
+def test_ragged_frames_match_oracle(size):
+    """Frames that are not whole 8x8 tiles (the work queue hands out items outside the image) and ragged parts:
+    same bars as the full scenes, and three interleaved parts of an odd height reassemble to the full frame."""
+    from raytracer_amd import tiles
+    scene = small_dragons(32, 24)
+    cam = scene.camera(*size)
+    g = scene.build(host.new_world(0)).render(cam, aux=True)
+    r = scene.build(_oracle().new_world()).render(cam, aux=True)
+    check(g, r, f"small dragons {size}")
+    raw = Raw(scene, size)
+    full, ids, st = raw.render()
+    assert np.array_equal(full.view(np.uint32), g.rgb.view(np.uint32))
+    canvas, idc = np.empty_like(full), np.empty_like(ids)
+    for p in range(3):
+        rows = tiles.part_rows(size[1], 2, 3, p)
+        rgb, oid, _ = raw.render(tile_h=2, n_parts=3, part=p)
+        assert len(rgb) == len(rows)
+        canvas[rows], idc[rows] = rgb, oid
+    assert np.array_equal(canvas.view(np.uint32), full.view(np.uint32)) and np.array_equal(idc, ids)
+
+
 def test_accel_and_pruning_change_nothing_at_4k():
     """dragons at 4K (BASELINE config 5, synthetic mesh): the auxiliary BVHs and the distance pruning are
     pure culling — bit-identical image and ids with either or both switched off."""
