@@ -57,7 +57,7 @@ def main():
     ap.add_argument("--workload", default="dragons")
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
-    ap.add_argument("--tile-h", type=int, default=2)
+    ap.add_argument("--tile-h", type=int, default=8)  # a multiple of 8 keeps every 8x8 wave tile inside one stripe
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-pixels", type=int, default=130000)
     args = ap.parse_args()

@@ -205,7 +205,8 @@ typedef struct {
   float jitter_value;
   uint64_t seed;
   /* interleaved scanline tiles (multi-GPU): this call renders the rows r with
-   * (r / tile_h) % n_parts == part, compacted in order.  n_parts = 1 renders everything. */
+   * (r / tile_h) % n_parts == part, compacted in order.  n_parts = 1 renders everything.  Prefer a tile_h that is
+   * a multiple of 8: the kernel works on 8x8 pixel tiles of the compacted rows. */
   uint32_t tile_h, n_parts, part;
   uint32_t flags; /* RT_RENDER_* */
 } RtRenderOptions;

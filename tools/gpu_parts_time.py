@@ -21,3 +21,7 @@ for W, H in ((3840, 2160), (7680, 4320), (1920, 1080), (960, 540)):
 for n in (2, 8):
     ts = [run(3840, 2160, n, p)[0] for p in range(n)]
     print(f"4K as {n} parts: each {[round(x, 3) for x in ts]} sum {sum(ts):.3f} ms", flush=True)
+for th in (8, 16, 32):
+    for n in (2, 8):
+        ts = [run(3840, 2160, n, p, th)[0] for p in range(n)]
+        print(f"tile_h {th}: 4K as {n} parts: each {[round(x, 3) for x in ts]} max {max(ts):.3f} ms", flush=True)
