@@ -190,6 +190,21 @@ def test_aux_bvh_is_well_formed(obj_files):
     assert np.array_equal(covered, in_sub.astype(int)), "every triangle of a covered subtree sits in exactly one leaf"
 
 
+def test_flatten_matches_committed_hashes(obj_files):
+    """tests/golden/flatten_hashes.json (tools/make_flatten_fixtures.py): the flattened RtScene of every config scene
+    is byte-for-byte what it was when the GPU path was validated against the oracle and the reference renders."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from make_flatten_fixtures import NAMES, flatten_hashes
+    want = json.load(open(os.path.join(ROOT, "tests", "golden", "flatten_hashes.json")))
+    assert sorted(want) == sorted(NAMES)
+    for name in NAMES:
+        got = flatten_hashes(name)
+        for k, v in want[name].items():
+            assert got[k] == v, f"{name}: flattened `{k}` changed"
+
+
 def test_scene_without_triangle_groups_has_no_aux():
     scene, hw, fs = _flat("cover")
     acc = abi.accel_arrays(host.hip_lib(), fs)
