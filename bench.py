@@ -59,7 +59,7 @@ def main():
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--tile-h", type=int, default=8)  # a multiple of 8 keeps every 8x8 wave tile inside one stripe
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-pixels", type=int, default=130000)
+    ap.add_argument("--cpu-sample-pixels", type=int, default=900000)  # ~15 s of oracle work on 16 threads
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
