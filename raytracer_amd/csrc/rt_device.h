@@ -367,46 +367,40 @@ __device__ __forceinline__ void load_tri(const Scene& sc, uint32_t prim, V3& p1,
 //  collect: every intersection with t <= tlimit (total order), for the n1/n2 container walk.
 // ---------------------------------------------------------------------------------------
 enum { SINK_CLOSEST = 0, SINK_COLLECT = 1, SINK_CLOSEST_NOSHADOW = 2, SINK_ANY_SHADOW = 3 };
+struct XsList {  // every intersection of a ray up to its hit: input of the n1/n2 walk
+  float t[RT_XS_CAP];
+  uint32_t s[RT_XS_CAP];
+};
+// Nine registers: the modes never need their private state at the same time, so it shares fields.
 struct Sink {
-  float t, u, v;
-  int shape;
-  float* ts;
-  uint32_t* ss;
-  int n;
-  int overflow;
-  float tlimit;   // collect: keep t <= tlimit; any-shadow: distance to the light
-  float tF;       // any-shadow: nearest hit on a shadow-less shape (inf if none) ...
-  int sF;         // ... and its shape
-  float tcap;     // closest: upper bound of interest (inf, or the distance to the light)
+  float t;       // closest: best t so far (inf if none)
+  int shape;     // closest: its shape (-1 if none)
+  float a;       // closest: u of the best hit          | any-shadow: tF, nearest hit on a shadow-less shape (inf if none)
+  float b;       // closest: v of the best hit
+  int c;         // collect: entries stored (> RT_XS_CAP: the list overflowed) | any-shadow: sF, the shape of tF
+  XsList* xs;    // collect: where the entries go
+  float bound;   // collect: keep t <= bound | any-shadow: distance to the light | closest: nothing at or beyond it matters
   int mode;
-  bool found;     // any-shadow: an occluder has been found, the traversal may stop
-  float lim;      // nothing beyond this t can matter any more (kept up to date by add)
+  float lim;     // nothing beyond this t can matter any more (kept up to date by add); -inf: any-shadow found its occluder
   __device__ __forceinline__ void init(int mode_) {
     t = __builtin_inff();
-    u = v = 0.f;
     shape = -1;
-    ts = nullptr;
-    ss = nullptr;
-    n = 0;
-    overflow = 0;
-    tlimit = 0.f;
-    tF = __builtin_inff();
-    sF = -1;
-    tcap = __builtin_inff();
+    a = b = 0.f;
+    c = 0;
+    xs = nullptr;
+    bound = __builtin_inff();
     mode = mode_;
-    found = false;
     lim = __builtin_inff();
   }
+  __device__ __forceinline__ void init_closest() { init(SINK_CLOSEST); }
   __device__ __forceinline__ void set_cap(float cap) {  // closest: nothing at or beyond cap can matter (shadow rays)
-    tcap = cap;
+    bound = cap;
     lim = __builtin_fminf(t, cap);
   }
-  __device__ __forceinline__ void init_closest() { init(SINK_CLOSEST); }
-  __device__ __forceinline__ void init_collect(float* ts_, uint32_t* ss_, float tlimit_) {
+  __device__ __forceinline__ void init_collect(XsList* xs_, float tlimit_) {
     init(SINK_COLLECT);
-    ts = ts_;
-    ss = ss_;
-    tlimit = tlimit_;
+    xs = xs_;
+    bound = tlimit_;
     lim = tlimit_;
   }
   // World::is_shadowed (world.rs:101-111) looks at the closest hit h* only: shadowed <=> t* < distance and
@@ -415,11 +409,16 @@ struct Sink {
   // (SINK_CLOSEST_NOSHADOW, only where such shapes exist), then any x ends the search (SINK_ANY_SHADOW).
   __device__ __forceinline__ void init_any_shadow(float distance, float tF_, int sF_) {
     init(SINK_ANY_SHADOW);
-    tlimit = distance;
-    tF = tF_;
-    sF = sF_;
+    bound = distance;
+    a = tF_;
+    c = sF_;
     lim = __builtin_fminf(distance, tF_);
   }
+  __device__ __forceinline__ float u() const { return a; }
+  __device__ __forceinline__ float v() const { return b; }
+  __device__ __forceinline__ bool found() const { return lim == -__builtin_inff(); }
+  __device__ __forceinline__ int count() const { return c > RT_XS_CAP ? RT_XS_CAP : c; }
+  __device__ __forceinline__ int overflow() const { return c > RT_XS_CAP ? 1 : 0; }
   // does this traversal look at a shape with these flags at all?
   __device__ __forceinline__ bool takes(uint32_t kind_flags) const {
     if (mode == SINK_CLOSEST_NOSHADOW) return !(kind_flags & RT_SHAPE_SHADOW);
@@ -427,36 +426,34 @@ struct Sink {
     return true;
   }
   __device__ __forceinline__ bool wants(float tt, uint32_t s) const {
-    if (mode == SINK_COLLECT) return !of_gt(tt, tlimit);
+    if (mode == SINK_COLLECT) return !of_gt(tt, bound);
     if (mode == SINK_ANY_SHADOW)
-      return !found && tt > 0.f && tt < tlimit && (sF < 0 || tt < tF || (tt == tF && (int)s < sF));
+      return !found() && tt > 0.f && tt < bound && (c < 0 || tt < a || (tt == a && (int)s < c));
     return tt > 0.f && (shape < 0 || tt < t || (tt == t && (int)s < shape));
   }
   __device__ __forceinline__ void add(float tt, uint32_t s, float uu, float vv) {
     if (!wants(tt, s)) return;
     if (mode == SINK_COLLECT) {
-      if (n < RT_XS_CAP) {
-        ts[n] = tt;
-        ss[n] = s;
-        n++;
+      if (c < RT_XS_CAP) {
+        xs->t[c] = tt;
+        xs->s[c] = s;
+        c++;
       } else {
-        overflow = 1;
+        c = RT_XS_CAP + 1;
       }
     } else if (mode == SINK_ANY_SHADOW) {
-      found = true;
       lim = -__builtin_inff();
     } else {
-      lim = __builtin_fminf(tt, tcap);
+      lim = __builtin_fminf(tt, bound);
       t = tt;
       shape = (int)s;
-      u = uu;
-      v = vv;
+      a = uu;
+      b = vv;
     }
   }
-  // nothing beyond this t can matter any more
   __device__ __forceinline__ float limit() const { return lim; }
   __device__ __forceinline__ bool wants_negative() const { return mode == SINK_COLLECT; }
-  __device__ __forceinline__ bool done() const { return mode == SINK_ANY_SHADOW && found; }
+  __device__ __forceinline__ bool done() const { return mode == SINK_ANY_SHADOW && found(); }
 };
 
 // Shape::intersect (shapes.rs:204-246): inverse-transform the ray, dispatch on kind.
@@ -1241,8 +1238,7 @@ template <bool COUNT, class Source>
 __device__ inline void integrate(const Scene& sc, const RenderParams& rp, const Source& src, uint32_t remaining0,
                                  unsigned long long* queue, Counters& cn) {
   PendingRay stack[RT_MAX_RAY_STACK];
-  float xs_t[RT_XS_CAP];
-  uint32_t xs_s[RT_XS_CAP];
+  XsList xl;
   Park pk{threadIdx.x};
   int sp = 0;
   bool first = true;
@@ -1312,7 +1308,7 @@ __device__ inline void integrate(const Scene& sc, const RenderParams& rp, const 
     // ---------------- the one traversal ----------------
     Sink sink;
     if (job == JOB_COLLECT)
-      sink.init_collect(xs_t, xs_s, hit_t);
+      sink.init_collect(&xl, hit_t);
     else if (job == JOB_SHADOW && (sc.props & RT_SCENE_HAS_NOSHADOW) && !(sc.props & RT_SCENE_SHADOW_TWO_PASS)) {
       sink.init_closest();  // small scene with shadow-less shapes: one closest-hit pass, capped at the light
       sink.set_cap(distance);
@@ -1340,7 +1336,7 @@ __device__ inline void integrate(const Scene& sc, const RenderParams& rp, const 
     if (!active) {
       // idle lane: nothing was traced for it
     } else if (job == JOB_SHADE) {
-      Hit hit = Hit{sink.t, sink.u, sink.v, sink.shape};
+      Hit hit = Hit{sink.t, sink.u(), sink.v(), sink.shape};
       if (first) {
         primary_hit = hit;
         first = false;
@@ -1401,7 +1397,7 @@ __device__ inline void integrate(const Scene& sc, const RenderParams& rp, const 
     } else if (job == JOB_SHADOW) {
       // World::is_shadowed (world.rs:101-111): closest-hit semantics, see Sink::init_any_shadow
       bool shadowed = sink.mode == SINK_ANY_SHADOW
-                          ? sink.found
+                          ? sink.found()
                           : (sink.shape >= 0 && sink.t < distance && (sc.shapes[sink.shape].kind_flags & RT_SHAPE_SHADOW));
       const RtLight& L = sc.lights[li];
       const RtMaterial& m = sc.materials[mat_id];
@@ -1453,8 +1449,8 @@ __device__ inline void integrate(const Scene& sc, const RenderParams& rp, const 
         }
       }
     } else {  // JOB_COLLECT
-      cn.overflow += sink.overflow;
-      refractive_indices(sc, xs_t, xs_s, sink.n, hit_t, hit_shape, n1, n2);
+      cn.overflow += sink.overflow();
+      refractive_indices(sc, xl.t, xl.s, sink.count(), hit_t, hit_shape, n1, n2);
       st = ST_SECONDARY;
     }
 
@@ -1609,7 +1605,7 @@ __device__ __forceinline__ Hit direct_closest(const Scene& sc, const Ray& ray, C
   Sink sink;
   sink.init_closest();
   simple_intersect<COUNT>(sc, ray, sink, cn);
-  return Hit{sink.t, sink.u, sink.v, sink.shape};
+  return Hit{sink.t, sink.u(), sink.v(), sink.shape};
 }
 // World::is_shadowed (world.rs:101-111), see Sink::init_any_shadow for the two equivalent searches
 template <bool COUNT>
@@ -1627,7 +1623,7 @@ __device__ __forceinline__ bool direct_is_shadowed(const Scene& sc, V3 light_pos
   }
   sink.init_any_shadow(distance, __builtin_inff(), -1);
   simple_intersect<COUNT>(sc, Ray{p, direction}, sink, cn);
-  return sink.found;
+  return sink.found();
 }
 
 template <bool COUNT>
@@ -1737,13 +1733,12 @@ __device__ inline V3 color_at_direct(const Scene& sc, const RenderParams& rp, Ra
     float reflectance = 1.f, transmittance = 1.f;
     float n1 = 1.f, n2 = 1.f;
     if (want_refract && !(sc.props & RT_SCENE_RI_ALL_ONE)) {
-      float xs_t[RT_XS_CAP];
-      uint32_t xs_s[RT_XS_CAP];
+      XsList xl;
       Sink cs;
-      cs.init_collect(xs_t, xs_s, hit.t);
+      cs.init_collect(&xl, hit.t);
       simple_intersect<COUNT>(sc, ray, cs, cn);
-      cn.overflow += cs.overflow;
-      refractive_indices(sc, xs_t, xs_s, cs.n, hit.t, hit.shape, n1, n2);
+      cn.overflow += cs.overflow();
+      refractive_indices(sc, xl.t, xl.s, cs.count(), hit.t, hit.shape, n1, n2);
     }
     if (m_reflective > 0.f && m_transparency > 0.f) {  // Computations::schlick (intersections.rs:177-192)
       float cosv = dot(eyev, normalv);
