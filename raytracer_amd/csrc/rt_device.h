@@ -1226,8 +1226,8 @@ __device__ __forceinline__ void pk_st3(const Park& pk, int k, V3 x) {
 // mixes pixels of different tiles in one wave, and the loss of coherence in the traversal costs more than the idle
 // lanes did (4.8 / 4.7 / 4.5 / 4.3 ms for 1 / 8 / 32 / 64), so the default is 64: a wave takes a whole 8x8 tile
 // (64 consecutive items) when all its lanes are done.
-// `Source` supplies the work: total(), start(item, ray, id) -> false if the item is outside the image, and
-// finish(item, colour, primary hit, work).  `queue` is a zeroed counter in device memory.
+// `Source` supplies the work: total(), start(item, ray) -> false if the item is outside the image, id(item) (the key
+// of the item's random numbers), first_hit(item, hit) and finish(item, colour, work).  `queue` is a zeroed counter in device memory.
 // Every wave leaves the loop: each refill advances the queue, and a wave whose lanes are all idle either refills
 // or, once the queue has run past total(), breaks.
 #ifndef RT_REFILL_MIN
@@ -1245,8 +1245,7 @@ __device__ inline void integrate(const Scene& sc, const RenderParams& rp, const 
   const float nl = (float)sc.n_lights;
   const uint32_t n_items = src.total();
   bool exhausted = false;  // wave-uniform: the queue has run past the last item
-  uint32_t item = 0, pixel = 0, work_start = 0;
-  Hit primary_hit{0.f, 0.f, 0.f, -1};
+  uint32_t item = 0, work_start = 0;
 
   // the hit being shaded: with the parked ray, enough to rebuild what Computations::prepare holds
   uint32_t remaining = 0u, path = 1u;
@@ -1281,7 +1280,7 @@ __device__ inline void integrate(const Scene& sc, const RenderParams& rp, const 
           const uint32_t rank = (uint32_t)__builtin_popcountll(idle & ((1ull << lane) - 1ull));
           const unsigned long long want = base + rank;
           Ray primary;
-          if (want < n_items && src.start((uint32_t)want, primary, pixel)) {
+          if (want < n_items && src.start((uint32_t)want, primary)) {
             item = (uint32_t)want;
             cn.primary++;
             pk_st3(pk, PK_RESULT, v3(0.f, 0.f, 0.f));
@@ -1338,7 +1337,7 @@ __device__ inline void integrate(const Scene& sc, const RenderParams& rp, const 
     } else if (job == JOB_SHADE) {
       Hit hit = Hit{sink.t, sink.u(), sink.v(), sink.shape};
       if (first) {
-        primary_hit = hit;
+        src.first_hit(item, hit);  // outputs of the primary hit go out now instead of riding along in registers
         first = false;
       }
       hit_t = hit.t;
@@ -1433,7 +1432,7 @@ __device__ inline void integrate(const Scene& sc, const RenderParams& rp, const 
           V3 sum = v3(0.f, 0.f, 0.f);
           for (uint32_t u = 0; u < L.usteps; u++)
             for (uint32_t v = 0; v < L.vsteps; v++) {
-              V3 lpos = point_on_light(L, li, u, v, 1u, rp, pixel, path);
+              V3 lpos = point_on_light(L, li, u, v, 1u, rp, src.id(item), path);
               V3 diffuse, specular;
               if (phong_sample(lpos, over_point, eyev, normalv, effective, lcol, m_diffuse, m_specular, m_shininess,
                                diffuse, specular))
@@ -1464,7 +1463,7 @@ __device__ inline void integrate(const Scene& sc, const RenderParams& rp, const 
             lpos = v3(L.position[0], L.position[1], L.position[2]);
           } else {
             uint32_t u = sample / L.vsteps, v = sample % L.vsteps;  // u outer, v inner (lights.rs:125-126)
-            lpos = point_on_light(L, li, u, v, 0u, rp, pixel, path);
+            lpos = point_on_light(L, li, u, v, 0u, rp, src.id(item), path);
           }
           const V3 over_point = (pk_ld3(pk, PK_SRAY_O) + hit_t * pk_ld3(pk, PK_SRAY_D)) + 1e-4f * normalv;
           V3 v = lpos - over_point;
@@ -1572,7 +1571,7 @@ __device__ inline void integrate(const Scene& sc, const RenderParams& rp, const 
     }
     if (st == ST_DONE) {
       const uint32_t work = COUNT ? cn.node_visits + cn.aux_tests + cn.tri_tests + cn.shape_tests - work_start : 0u;
-      src.finish(item, pk_ld3(pk, PK_RESULT), primary_hit, work, cn);
+      src.finish(item, pk_ld3(pk, PK_RESULT), work, cn);
       st = ST_IDLE;
     }
   }

@@ -96,20 +96,19 @@ struct PixelOut {
   int32_t* __restrict__ oid;
   float* __restrict__ ht;
 };
+__device__ __forceinline__ void write_hit(const PixelOut& o, size_t idx, const Hit& ph) {
+  if (o.mask) o.mask[idx] = ph.shape >= 0 ? 1 : 0;
+  if (o.oid) o.oid[idx] = ph.shape;
+  if (o.ht) o.ht[idx] = ph.shape >= 0 ? ph.t : __builtin_nanf("");
+}
 template <bool COUNT>
-__device__ __forceinline__ void write_pixel(const Scene& sc, const PixelOut& o, size_t idx, V3 col, const Hit& ph, float work,
-                                            float work_shadow, float work_collect) {
+__device__ __forceinline__ void write_colour(const Scene& sc, const PixelOut& o, size_t idx, V3 col, float work,
+                                             float work_shadow, float work_collect) {
   o.out[3 * idx + 0] = col.x;
   o.out[3 * idx + 1] = col.y;
   o.out[3 * idx + 2] = col.z;
-  if (o.mask) o.mask[idx] = ph.shape >= 0 ? 1 : 0;
-  if (o.oid) o.oid[idx] = ph.shape;
-  if (o.ht) {
-    if (COUNT && (sc.flags & RT_RENDER_WORK_MAP))  // diagnostics: this pixel's traversal work instead of hit t
-      o.ht[idx] = (sc.flags & 0x10u) ? work_shadow : (sc.flags & 0x20u) ? work_collect : work;
-    else
-      o.ht[idx] = ph.shape >= 0 ? ph.t : __builtin_nanf("");
-  }
+  if (COUNT && o.ht && (sc.flags & RT_RENDER_WORK_MAP))  // diagnostics: this pixel's traversal work instead of hit t
+    o.ht[idx] = (sc.flags & 0x10u) ? work_shadow : (sc.flags & 0x20u) ? work_collect : work;
 }
 // work items of a frame: pixel `item & 63` of 8x8 tile `item >> 6`, tiles in row-major order
 template <bool COUNT>
@@ -125,16 +124,27 @@ struct PixelSource {
     px = (tile % tiles_x) * 8u + (w & 7u);
     ly = (tile / tiles_x) * 8u + (w >> 3);
   }
-  __device__ bool start(uint32_t item, Ray& r, uint32_t& pixel) const {
+  __device__ uint32_t global_row(uint32_t ly) const {
+    return (ly / part.tile_h) * (part.n_parts * part.tile_h) + part.part * part.tile_h + (ly % part.tile_h);
+  }
+  __device__ bool start(uint32_t item, Ray& r) const {
     uint32_t px, ly;
     locate(item, px, ly);
     if (px >= cam.hsize || ly >= part.rows) return false;
-    const uint32_t py = (ly / part.tile_h) * (part.n_parts * part.tile_h) + part.part * part.tile_h + (ly % part.tile_h);
-    r = ray_for_pixel(cam, px, py);
-    pixel = py * cam.hsize + px;
+    r = ray_for_pixel(cam, px, global_row(ly));
     return true;
   }
-  __device__ void finish(uint32_t item, V3 col, const Hit& ph, uint32_t work, Counters& cn) const {
+  __device__ uint32_t id(uint32_t item) const {  // absolute pixel: the same random numbers whatever the partition
+    uint32_t px, ly;
+    locate(item, px, ly);
+    return global_row(ly) * cam.hsize + px;
+  }
+  __device__ void first_hit(uint32_t item, const Hit& ph) const {
+    uint32_t px, ly;
+    locate(item, px, ly);
+    write_hit(o, (size_t)ly * cam.hsize + px, ph);
+  }
+  __device__ void finish(uint32_t item, V3 col, uint32_t work, Counters& cn) const {
     uint32_t px, ly;
     locate(item, px, ly);
     float ws = 0.f, wc = 0.f;
@@ -143,7 +153,7 @@ struct PixelSource {
       cn.work_shadow = 0;
       cn.work_collect = 0;
     }
-    write_pixel<COUNT>(*sc, o, (size_t)ly * cam.hsize + px, col, ph, (float)work, ws, wc);
+    write_colour<COUNT>(*sc, o, (size_t)ly * cam.hsize + px, col, (float)work, ws, wc);
   }
 };
 template <bool COUNT>
@@ -178,9 +188,10 @@ void k_render_direct(Scene sc, RtCamera cam, RenderParams rp, PartInfo part, Pix
     cn.primary = 1;
     Hit ph;
     V3 col = color_at_direct<COUNT>(sc, rp, ray_for_pixel(cam, px, py), sc.recursion_limit, py * cam.hsize + px, cn, &ph);
-    write_pixel<COUNT>(sc, o, (size_t)ly * cam.hsize + px, col, ph,
-                       (float)(cn.node_visits + cn.aux_tests + cn.tri_tests + cn.shape_tests), (float)cn.work_shadow,
-                       (float)cn.work_collect);
+    write_hit(o, (size_t)ly * cam.hsize + px, ph);
+    write_colour<COUNT>(sc, o, (size_t)ly * cam.hsize + px, col,
+                        (float)(cn.node_visits + cn.aux_tests + cn.tri_tests + cn.shape_tests), (float)cn.work_shadow,
+                        (float)cn.work_collect);
   }
   flush_counters(cn, counters);
 }
@@ -195,12 +206,14 @@ struct RayOut {
   int32_t* __restrict__ hit_id;
   float* __restrict__ hit_uv;
 };
-__device__ __forceinline__ void write_ray(const RayOut& o, uint32_t i, V3 col, const Hit& ph) {
+__device__ __forceinline__ void write_ray_colour(const RayOut& o, uint32_t i, V3 col) {
   if (o.out) {
     o.out[3 * i] = col.x;
     o.out[3 * i + 1] = col.y;
     o.out[3 * i + 2] = col.z;
   }
+}
+__device__ __forceinline__ void write_ray_hit(const RayOut& o, uint32_t i, const Hit& ph) {
   if (o.hit_t) o.hit_t[i] = ph.shape >= 0 ? ph.t : __builtin_nanf("");
   if (o.hit_id) o.hit_id[i] = ph.shape;
   if (o.hit_uv) {
@@ -211,13 +224,14 @@ __device__ __forceinline__ void write_ray(const RayOut& o, uint32_t i, V3 col, c
 struct RaySource {
   RayOut o;
   __device__ uint32_t total() const { return o.n; }
-  __device__ bool start(uint32_t i, Ray& r, uint32_t& pixel) const {
+  __device__ bool start(uint32_t i, Ray& r) const {
     r = Ray{v3(o.origins[3 * i], o.origins[3 * i + 1], o.origins[3 * i + 2]),
             v3(o.directions[3 * i], o.directions[3 * i + 1], o.directions[3 * i + 2])};
-    pixel = i;
     return true;
   }
-  __device__ void finish(uint32_t i, V3 col, const Hit& ph, uint32_t, Counters&) const { write_ray(o, i, col, ph); }
+  __device__ uint32_t id(uint32_t i) const { return i; }
+  __device__ void first_hit(uint32_t i, const Hit& ph) const { write_ray_hit(o, i, ph); }
+  __device__ void finish(uint32_t i, V3 col, uint32_t, Counters&) const { write_ray_colour(o, i, col); }
 };
 template <bool COUNT>
 __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAVES_PER_EU, RT_WAVES_PER_EU)))
@@ -237,7 +251,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_color_at_direct(Scene sc, RenderPa
     cn.primary = 1;
     Hit ph;
     V3 col = color_at_direct<false>(sc, rp, r, remaining, i, cn, &ph);
-    write_ray(o, i, col, ph);
+    write_ray_colour(o, i, col);
+    write_ray_hit(o, i, ph);
   }
   flush_counters(cn, counters);
 }
