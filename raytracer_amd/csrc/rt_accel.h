@@ -20,9 +20,9 @@
 //      least one |d| >= 1e-4 component).  gate_next[] lists the groups whose test is NOT implied.
 //
 // Layout (device, 80 B per node, 16 B aligned):
-//   aux[root]      header: {cx, cy, cz, radius} {lmax, amax, 0, 0} {unused} {unused} {unused}
+//   aux[root]      entry record of one instance: {cx, cy, cz, radius} {lmax, amax, top node index, first shape}
 //                  (centre/radius of the padded boxes, longest edge, largest |e1|*|e2|)
-//   aux[root + 1]  top node; every node holds the boxes of BOTH children and its own normal cone:
+//   aux[top]       top node of the (possibly shared) tree; every node holds the boxes of BOTH children and its own normal cone:
 //     {lmin.xyz, left}  {lmax.xyz, lcount}  {rmin.xyz, right}  {rmax.xyz, rcount}  {a.xyz, cos w}
 //     cone: every triangle below the node has its unit normal within angle w of a/|a|, and
 //     1/sin(angle between its edges e1, e2) <= 1/|a|; cos w < -1 means "no bound".  The traversal turns
@@ -30,7 +30,8 @@
 //     sets how far its child boxes must be widened for this ray (rule 1).
 //     count == 0: child is the node aux[left]; count > 0: child is the leaf
 //     aux_tris[left .. left+count), 3 float4 per triangle:
-//       {p1.xyz, shape index} {e1.xyz, owning node index} {e2.xyz, shape kind_flags}   (as uint bits)
+//       {p1.xyz, shape index - first shape of the instance} {e1.xyz, owning node index - root node}
+//       {e2.xyz, shape kind_flags}   (as uint bits)
 #pragma once
 
 #include <algorithm>
@@ -354,16 +355,77 @@ inline Result build(const RtScene* s) {
     bool inside_parent = n.parent >= 0 && sub_ok[n.parent] && n.xform == 0;
     if (sub_ok[i] && !inside_parent) roots.push_back(i);
   }
+  // Instancing: subtrees with the same triangles in the same arrangement (the reference re-parses and duplicates an
+  // OBJ file for every instance, scene.rs:593-599) share one tree.  Leaf triangles hold the shape index relative to
+  // the instance's first shape and the owning group relative to the instance's root; every root gets its own
+  // 80-B entry record {centre, radius}{lmax, amax, index of the tree's top node, first shape of the instance}.
+  struct Inst {
+    uint32_t n_items = 0, shape_base = 0;
+    uint64_t hash = 0;
+    size_t same_as = 0;  // index into roots of the instance whose tree this one uses
+  };
+  auto for_items = [&](uint32_t R, auto&& f) {
+    for (uint32_t i = R; i < s->nodes[R].skip; i++) {
+      const RtNode& n = s->nodes[i];
+      for (uint32_t k = 0; k < n.n_shapes; k++) f(n.first_tri + k, n.first_shape + k, i);
+    }
+  };
+  std::vector<Inst> inst(roots.size());
+  for (size_t j = 0; j < roots.size(); j++) {
+    Inst& I = inst[j];
+    I.same_as = j;
+    I.shape_base = 0xFFFFFFFFu;
+    for_items(roots[j], [&](uint32_t, uint32_t shape, uint32_t) { I.shape_base = std::min(I.shape_base, shape), I.n_items++; });
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](const void* p, size_t n) {
+      const unsigned char* c = static_cast<const unsigned char*>(p);
+      for (size_t q = 0; q < n; q++) h = (h ^ c[q]) * 1099511628211ull;
+    };
+    for_items(roots[j], [&](uint32_t tri, uint32_t shape, uint32_t owner) {
+      uint32_t rel[3] = {shape - I.shape_base, owner - roots[j], s->shapes[shape].kind_flags};
+      mix(&s->tri_geom[tri], sizeof(RtTriGeom));
+      mix(rel, sizeof(rel));
+    });
+    I.hash = h;
+  }
+  auto same_items = [&](size_t j1, size_t j2) {  // full comparison behind a hash match
+    if (inst[j1].n_items != inst[j2].n_items) return false;
+    std::vector<uint32_t> t1, t2;
+    for_items(roots[j1], [&](uint32_t tri, uint32_t shape, uint32_t owner) {
+      t1.push_back(tri), t1.push_back(shape - inst[j1].shape_base), t1.push_back(owner - roots[j1]),
+          t1.push_back(s->shapes[shape].kind_flags);
+    });
+    for_items(roots[j2], [&](uint32_t tri, uint32_t shape, uint32_t owner) {
+      t2.push_back(tri), t2.push_back(shape - inst[j2].shape_base), t2.push_back(owner - roots[j2]),
+          t2.push_back(s->shapes[shape].kind_flags);
+    });
+    for (size_t q = 0; q < t1.size(); q += 4) {
+      if (t1[q + 1] != t2[q + 1] || t1[q + 2] != t2[q + 2] || t1[q + 3] != t2[q + 3]) return false;
+      if (std::memcmp(&s->tri_geom[t1[q]], &s->tri_geom[t2[q]], sizeof(RtTriGeom)) != 0) return false;
+    }
+    return true;
+  };
+  for (size_t j = 1; j < roots.size(); j++)
+    for (size_t q = 0; q < j; q++)
+      if (inst[q].same_as == q && inst[q].hash == inst[j].hash && same_items(q, j)) {
+        inst[j].same_as = q;
+        break;
+      }
   struct Out {
     std::vector<Node> nodes;
     std::vector<Tri> tris;
     bool ok = false;
+    uint32_t top = 0;  // index of the top node in Result::nodes
   };
   std::vector<Out> outs(roots.size());
+  std::vector<size_t> todo;
+  for (size_t j = 0; j < roots.size(); j++)
+    if (inst[j].same_as == j) todo.push_back(j);
   unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-  if (roots.size() < 2) nt = 1;
+  if (todo.size() < 2) nt = 1;
   auto work = [&](unsigned t) {
-    for (size_t j = t; j < roots.size(); j += nt) {
+    for (size_t w = t; w < todo.size(); w += nt) {
+      const size_t j = todo[w];
       uint32_t R = roots[j];
       TreeBuilder tb;
       tb.geom = s->tri_geom;
@@ -384,21 +446,38 @@ inline Result build(const RtScene* s) {
   for (unsigned t = 1; t < nt; t++) th.emplace_back(work, t);
   work(0);
   for (auto& t : th) t.join();
-  for (size_t j = 0; j < roots.size(); j++) {
+  // the trees, without their headers; leaf triangles made relative to the instance
+  for (size_t j : todo) {
     if (!outs[j].ok) continue;
     uint64_t nb = r.nodes.size(), tbase = r.tris.size();
-    if (nb + outs[j].nodes.size() >= 0x1FFFFFFFull || tbase + outs[j].tris.size() >= 0x1FFFFFFFull) break;
-    uint32_t R = roots[j];
-    r.root_of[R] = (uint32_t)nb;
-    for (size_t q = 0; q < outs[j].nodes.size(); q++) {
+    // references are (index << 3 | count): indices stay below 2^29
+    if (nb + outs[j].nodes.size() + roots.size() >= 0x1FFFFFFFull || tbase + outs[j].tris.size() >= 0x1FFFFFFFull) {
+      outs[j].ok = false;
+      continue;
+    }
+    outs[j].top = (uint32_t)nb;
+    for (size_t q = 1; q < outs[j].nodes.size(); q++) {  // local index q (header at 0) -> nb + q - 1
       Node nd = outs[j].nodes[q];
-      if (q > 0) {
-        nd.left += (uint32_t)(nd.lcount ? tbase : nb);
-        nd.right += (uint32_t)(nd.rcount ? tbase : nb);
-      }
+      nd.left = (uint32_t)(nd.lcount ? tbase + nd.left : nb + nd.left - 1);
+      nd.right = (uint32_t)(nd.rcount ? tbase + nd.right : nb + nd.right - 1);
       r.nodes.push_back(nd);
     }
-    r.tris.insert(r.tris.end(), outs[j].tris.begin(), outs[j].tris.end());
+    for (Tri t : outs[j].tris) {
+      t.shape -= inst[j].shape_base;
+      t.owner -= roots[j];
+      r.tris.push_back(t);
+    }
+  }
+  // one entry record per root
+  for (size_t j = 0; j < roots.size(); j++) {
+    const Out& o = outs[inst[j].same_as];
+    if (!o.ok) continue;
+    uint32_t R = roots[j];
+    Node h = o.nodes[0];
+    std::memcpy(&h.lmax[2], &o.top, 4);
+    h.lcount = inst[j].shape_base;
+    r.root_of[R] = (uint32_t)r.nodes.size();
+    r.nodes.push_back(h);
     // gate chains: gate_next[c] = nearest proper ancestor A below R whose test is not implied by the
     // tests already made on the way up, i.e. the node just below A on the path is not nested in A.
     for (uint32_t c = R + 1; c < s->nodes[R].skip; c++) {

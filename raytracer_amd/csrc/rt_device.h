@@ -666,7 +666,10 @@ __device__ inline bool aux_intersect(const Scene& sc, uint32_t root_node, uint32
   V3 inv = v3(__builtin_amdgcn_rcpf(cur.d.x), __builtin_amdgcn_rcpf(cur.d.y), __builtin_amdgcn_rcpf(cur.d.z));
   uint32_t* stk = aux_stack();
   int sp = 0;
-  uint32_t ref = (aux_root + 1u) << 3;
+  // entry record: {centre, radius}{lmax, amax, top node, first shape of this instance}; the tree may be shared
+  // between instances, so its leaves hold shape and group indices relative to the instance
+  const uint32_t shape_base = __float_as_uint(h1.w);
+  uint32_t ref = __float_as_uint(h1.z) << 3;
   // the computed t of an accepted hit lies within 13u * K * |s| / |d| < 0.55 * pad / |d| of the line's true
   // crossing of the triangle's plane, which is inside the widened box: slack for the t-range pruning
   const float lo0 = sink.wants_negative() ? -__builtin_inff() : 0.f;
@@ -730,8 +733,8 @@ __device__ inline bool aux_intersect(const Scene& sc, uint32_t root_node, uint32
         float t, u, v;
         if (sink.takes(__float_as_uint(c.w)) &&
             isect_triangle(cur, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), v3(c.x, c.y, c.z), t, u, v)) {
-          uint32_t shape = __float_as_uint(a.w);
-          if (sink.wants(t, shape) && aux_gate<COUNT>(sc, __float_as_uint(b.w), root_node, cur, cn))
+          uint32_t shape = shape_base + __float_as_uint(a.w);
+          if (sink.wants(t, shape) && aux_gate<COUNT>(sc, root_node + __float_as_uint(b.w), root_node, cur, cn))
             sink.add(t, shape, u, v);
         }
       }

@@ -135,15 +135,18 @@ def test_aux_bvh_is_well_formed(obj_files):
     assert len(has) == 6  # dragons.yaml: six dragon.obj instances, each one covered subtree
     an, at = acc["nodes"], acc["tris"]
     covered = np.zeros(len(shapes), dtype=int)
+    tops = set()
     for R in has:
         R = int(R)
         end = int(nodes["skip"][R])
         sub = np.arange(R, end)
         assert np.all(nodes["xform"][R + 1:end] == 0), "only the subtree root may carry a transform"
         n_tris = int(nodes["n_shapes"][sub].sum())
-        hdr = an[roots[R]]
+        hdr = an[roots[R]]  # entry record of this instance: {centre, radius}{lmax, amax, top node, first shape}
         radius = hdr["left"].view(np.float32)
-        stack = [(int(roots[R]) + 1, 0, np.full(3, -np.inf), np.full(3, np.inf))]
+        top, shape_base = int(hdr["lmax"][2:3].view(np.uint32)[0]), int(hdr["lcount"])
+        tops.add(top)
+        stack = [(top, 0, np.full(3, -np.inf), np.full(3, np.inf))]
         depth_max, seen = 0, 0
         while stack:
             idx, depth, lo, hi = stack.pop()
@@ -158,7 +161,7 @@ def test_aux_bvh_is_well_formed(obj_files):
                     continue
                 assert 1 <= cnt <= 7
                 for t in at[ref:ref + cnt]:
-                    si, owner = int(t["shape"]), int(t["owner"])
+                    si, owner = shape_base + int(t["shape"]), R + int(t["owner"])  # leaves are instance-relative
                     covered[si] += 1
                     seen += 1
                     assert R <= owner < end and shapes["parent"][si] == owner
@@ -188,6 +191,7 @@ def test_aux_bvh_is_well_formed(obj_files):
             f, n = int(nodes["first_shape"][i]), int(nodes["n_shapes"][i])
             in_sub[f:f + n] = True
     assert np.array_equal(covered, in_sub.astype(int)), "every triangle of a covered subtree sits in exactly one leaf"
+    assert len(tops) == 1, "the six instances of dragon.obj share one tree"
 
 
 def test_flatten_matches_committed_hashes(obj_files):
