@@ -1629,7 +1629,7 @@ __device__ __forceinline__ bool direct_is_shadowed(const Scene& sc, V3 light_pos
 }
 
 template <bool COUNT>
-__device__ inline V3 color_at_direct(const Scene& sc, const RenderParams& rp, Ray primary, uint32_t remaining0,
+__device__ __forceinline__ V3 color_at_direct(const Scene& sc, const RenderParams& rp, Ray primary, uint32_t remaining0,
                               uint32_t pixel, Counters& cn, Hit* primary_hit) {
   PendingRay stack[RT_MAX_RAY_STACK];
   int sp = 0;
