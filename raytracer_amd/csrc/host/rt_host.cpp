@@ -16,6 +16,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <map>
@@ -300,26 +301,67 @@ RtbMaterial default_material() {  // src/materials.rs:19-33
 
 // Keys for value classes: raw bits with -0 folded onto +0; NaN poisons the key.
 struct KeyBuilder {
-  std::string bytes;
+  // the value of a shape / material / pattern as bytes (floats with -0 folded into +0, NaN noted): equal keys <=>
+  // the reference's derived `==`.  Fixed buffer: a key is built for every one of millions of triangles.
+  char bytes[320];
+  uint32_t len = 0;
   bool nan = false;
+  void put(const void* p) {
+    if (len + 4 > sizeof(bytes)) std::abort();  // longest key: smooth triangle, 4 + 16 + 2 + 15 + 9 words
+    std::memcpy(bytes + len, p, 4);
+    len += 4;
+  }
   void f(float v) {
     if (std::isnan(v)) nan = true;
     if (v == 0.f) v = 0.f;
-    bytes.append(reinterpret_cast<const char*>(&v), 4);
+    put(&v);
   }
   void fs(const float* v, int n) {
     for (int i = 0; i < n; i++) f(v[i]);
   }
-  void u(uint32_t v) { bytes.append(reinterpret_cast<const char*>(&v), 4); }
+  void u(uint32_t v) { put(&v); }
 };
+// Value classes: ids in first-seen order.  Open addressing over an arena of key bytes (an unordered_map of strings
+// spent ~10 s on the 5.2 M triangles of dragons.yaml).
 struct ClassTable {
-  std::unordered_map<std::string, uint32_t> ids;
+  std::vector<char> arena;
+  std::vector<uint64_t> where;  // per id: offset << 16 | length
+  std::vector<uint32_t> slots;  // id + 1, 0 = empty
   uint32_t next = 0;
+  static uint64_t hash(const char* p, uint32_t n) {
+    uint64_t h = 0x9E3779B97F4A7C15ull;
+    for (uint32_t i = 0; i + 4 <= n; i += 4) {
+      uint32_t w;
+      std::memcpy(&w, p + i, 4);
+      h = (h ^ w) * 0xFF51AFD7ED558CCDull;
+      h ^= h >> 29;
+    }
+    return h;
+  }
+  void grow() {
+    size_t cap = slots.empty() ? 1024 : slots.size() * 2;
+    std::vector<uint32_t> ns(cap, 0);
+    for (uint32_t id = 0; id < next; id++) {
+      uint64_t w = where[id];
+      size_t i = hash(arena.data() + (w >> 16), (uint32_t)(w & 0xFFFF)) & (cap - 1);
+      while (ns[i]) i = (i + 1) & (cap - 1);
+      ns[i] = id + 1;
+    }
+    slots.swap(ns);
+  }
   uint32_t get(const KeyBuilder& k) {
     if (k.nan) return RT_VCLASS_NEVER;
-    auto it = ids.find(k.bytes);
-    if (it != ids.end()) return it->second;
-    ids.emplace(k.bytes, next);
+    if ((size_t)(next + 1) * 2 > slots.size()) grow();
+    const size_t mask = slots.size() - 1;
+    size_t i = hash(k.bytes, k.len) & mask;
+    while (slots[i]) {
+      uint64_t w = where[slots[i] - 1];
+      if ((w & 0xFFFF) == k.len && std::memcmp(arena.data() + (w >> 16), k.bytes, k.len) == 0) return slots[i] - 1;
+      i = (i + 1) & mask;
+    }
+    where.push_back(((uint64_t)arena.size() << 16) | k.len);
+    arena.insert(arena.end(), k.bytes, k.bytes + k.len);
+    slots[i] = next + 1;
     return next++;
   }
 };
