@@ -265,12 +265,17 @@ __global__ __launch_bounds__(RT_BLOCK) void k_color_at_direct(Scene sc, RenderPa
 // =========================================================================================
 // host side of the ABI
 // =========================================================================================
+#define RT_MAX_BANDS 4  // rt_render renders a full frame as up to this many row bands, copying each back while the next renders
 struct RtContext {
   int device = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr, copy_stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  unsigned long long* d_counters = nullptr;
+  hipEvent_t ev_band[RT_MAX_BANDS] = {nullptr, nullptr, nullptr, nullptr};
+  unsigned long long* d_counters = nullptr;  // RT_N_COUNTERS slots for rt_render_device, then one block per band
   uint32_t n_cus = 256;
+  // frame buffers of rt_render, kept between calls (grow only)
+  void* d_frame[4] = {nullptr, nullptr, nullptr, nullptr};  // rgb, mask, object id, hit t
+  size_t frame_bytes[4] = {0, 0, 0, 0};
   std::string error;
 };
 struct RtDeviceScene {
@@ -405,9 +410,17 @@ RenderParams make_params(const RtRenderOptions* o) {
   return rp;
 }
 
-int read_stats(RtContext* ctx, hipStream_t stream, RtStats* stats, double total_ms) {
-  unsigned long long h[RT_N_COUNTERS];
-  HIP_TRY(ctx, hipMemcpyAsync(h, ctx->d_counters, sizeof(h), hipMemcpyDeviceToHost, stream));
+int read_stats(RtContext* ctx, hipStream_t stream, RtStats* stats, double total_ms, int n_blocks = 1,
+               const unsigned long long* d_first = nullptr) {
+  unsigned long long h[RT_N_COUNTERS], hb[RT_MAX_BANDS * RT_N_COUNTERS];
+  if (n_blocks < 1 || n_blocks > RT_MAX_BANDS) return fail(ctx, RT_E_ABI, "bad counter block count");
+  HIP_TRY(ctx, hipMemcpyAsync(hb, d_first ? d_first : ctx->d_counters, (size_t)n_blocks * sizeof(h), hipMemcpyDeviceToHost,
+                              stream));
+  HIP_TRY(ctx, hipStreamSynchronize(stream));
+  for (int k = 0; k < RT_N_COUNTERS; k++) {
+    h[k] = 0;
+    for (int b = 0; b < n_blocks; b++) h[k] += hb[b * RT_N_COUNTERS + k];
+  }
   HIP_TRY(ctx, hipStreamSynchronize(stream));
   float ms = 0.f;
   HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
@@ -463,7 +476,11 @@ int rt_context_create(int device, RtContext** out) {
   if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
   if ((e = hipEventCreate(&c->ev0)) != hipSuccess) return bail(e, "hipEventCreate");
   if ((e = hipEventCreate(&c->ev1)) != hipSuccess) return bail(e, "hipEventCreate");
-  if ((e = hipMalloc((void**)&c->d_counters, RT_N_COUNTERS * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc");
+  if ((e = hipMalloc((void**)&c->d_counters, (1 + RT_MAX_BANDS) * RT_N_COUNTERS * sizeof(unsigned long long))) != hipSuccess)
+    return bail(e, "hipMalloc");
+  if ((e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
+  for (int b = 0; b < RT_MAX_BANDS; b++)
+    if ((e = hipEventCreateWithFlags(&c->ev_band[b], hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
   *out = c;
   return RT_OK;
 }
@@ -472,6 +489,11 @@ void rt_context_destroy(RtContext* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->d_counters) (void)hipFree(c->d_counters);
+  for (void* p : c->d_frame)
+    if (p) (void)hipFree(p);
+  for (hipEvent_t ev : c->ev_band)
+    if (ev) (void)hipEventDestroy(ev);
+  if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -596,6 +618,33 @@ void rt_accel_free(RtAccelView* v) {
 
 uint32_t rt_part_rows(const RtCamera* cam, const RtRenderOptions* o) { return cam ? make_part(cam, o).rows : 0; }
 
+// One kernel launch: the rows of `part` into d_out_rgb / d_aux, counters (and the work queue) in `d_counters`.
+static int launch_part(RtContext* ctx, const Scene& sc, const RtCamera* cam, const RenderParams& rp, const PartInfo& part,
+                       float* d_out_rgb, const RtAux* d_aux, hipStream_t stream, unsigned long long* d_counters) {
+  HIP_TRY(ctx, hipMemsetAsync(d_counters, 0, RT_N_COUNTERS * sizeof(unsigned long long), stream));
+  if (part.rows == 0) return RT_OK;
+  // both integrators give the same bits; the direct one wins where an area light's sample loop dominates
+  const bool direct = sc.n_nodes == 0 && (sc.props & RT_SCENE_AREA_LIGHT);
+  const bool count = (sc.flags & RT_RENDER_COUNT_WORK) != 0;
+  PixelOut po{d_out_rgb, d_aux ? d_aux->hit_mask : nullptr, d_aux ? d_aux->object_id : nullptr,
+              d_aux ? d_aux->hit_t : nullptr};
+  if (direct) {
+    const uint32_t tile = RT_BLOCK == 256 ? 16u : 8u;
+    dim3 grid((cam->hsize + tile - 1) / tile, (part.rows + tile - 1) / tile);
+    hipLaunchKernelGGL(count ? k_render_direct<true> : k_render_direct<false>, grid, dim3(RT_BLOCK), 0, stream, sc, *cam,
+                       rp, part, po, d_counters);
+  } else {
+    // persistent waves: enough blocks to fill the device at four waves per SIMD, never more than the work
+    const uint64_t items = (uint64_t)((cam->hsize + 7u) / 8u) * ((part.rows + 7u) / 8u) * 64u;
+    if (items >= 0xFFFFFFFFull) return fail(ctx, RT_E_ABI, "image too large");
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>((items + RT_BLOCK - 1) / RT_BLOCK, (uint64_t)ctx->n_cus * RT_BLOCKS_PER_CU);
+    hipLaunchKernelGGL(count ? k_render_jobs<true> : k_render_jobs<false>, dim3(blocks), dim3(RT_BLOCK), 0, stream, sc,
+                       *cam, rp, part, po, d_counters);
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  return RT_OK;
+}
+
 int rt_render_device(RtContext* ctx, const RtDeviceScene* ds, const RtCamera* cam, const RtRenderOptions* opts,
                      float* d_out_rgb, RtAux* d_aux, void* stream_, RtStats* stats) {
   if (!ctx || !ds || !cam || !d_out_rgb) return RT_E_ABI;
@@ -609,95 +658,101 @@ int rt_render_device(RtContext* ctx, const RtDeviceScene* ds, const RtCamera* ca
   Scene sc = ds->sc;
   sc.flags = opts ? opts->flags : 0;
   RenderParams rp = make_params(opts);
-  HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, RT_N_COUNTERS * sizeof(unsigned long long), stream));
-  if (part.rows > 0) {
-    HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
-    // both integrators give the same bits; the direct one wins where an area light's sample loop dominates
-    const bool direct = sc.n_nodes == 0 && (sc.props & RT_SCENE_AREA_LIGHT);
-    const bool count = (sc.flags & RT_RENDER_COUNT_WORK) != 0;
-    PixelOut po{d_out_rgb, d_aux ? d_aux->hit_mask : nullptr, d_aux ? d_aux->object_id : nullptr,
-                d_aux ? d_aux->hit_t : nullptr};
-    if (direct) {
-      const uint32_t tile = RT_BLOCK == 256 ? 16u : 8u;
-      dim3 grid((cam->hsize + tile - 1) / tile, (part.rows + tile - 1) / tile);
-      hipLaunchKernelGGL(count ? k_render_direct<true> : k_render_direct<false>, grid, dim3(RT_BLOCK), 0, stream, sc, *cam,
-                         rp, part, po, ctx->d_counters);
-    } else {
-      // persistent waves: enough blocks to fill the device at four waves per SIMD, never more than the work
-      const uint64_t items = (uint64_t)((cam->hsize + 7u) / 8u) * ((part.rows + 7u) / 8u) * 64u;
-      if (items >= 0xFFFFFFFFull) return fail(ctx, RT_E_ABI, "image too large");
-      const uint32_t blocks = (uint32_t)std::min<uint64_t>((items + RT_BLOCK - 1) / RT_BLOCK, (uint64_t)ctx->n_cus * RT_BLOCKS_PER_CU);
-      hipLaunchKernelGGL(count ? k_render_jobs<true> : k_render_jobs<false>, dim3(blocks), dim3(RT_BLOCK), 0, stream, sc,
-                         *cam, rp, part, po, ctx->d_counters);
-    }
-    HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipEventRecord(ctx->ev1, stream));
-  } else {
-    HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
-    HIP_TRY(ctx, hipEventRecord(ctx->ev1, stream));
-  }
+  HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
+  int rc = launch_part(ctx, sc, cam, rp, part, d_out_rgb, d_aux, stream, ctx->d_counters);
+  if (rc != RT_OK) return rc;
+  HIP_TRY(ctx, hipEventRecord(ctx->ev1, stream));
   if (stats) {
     HIP_TRY(ctx, hipStreamSynchronize(stream));
     double total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    int rc = read_stats(ctx, stream, stats, total);
+    rc = read_stats(ctx, stream, stats, total);
     if (rc != RT_OK) return rc;
     if (stats->overflow) return fail(ctx, RT_E_OVERFLOW, "per-ray intersection list overflow");
   }
   return RT_OK;
 }
 
+// Host-memory entry point.  The frame buffers live in the context between calls; a full frame is rendered as up to
+// RT_MAX_BANDS bands of rows, each copied back on a second stream while the next one renders (the copy of a 4K
+// f32 frame takes longer than its kernel).
 int rt_render(RtContext* ctx, const RtDeviceScene* ds, const RtCamera* cam, const RtRenderOptions* opts,
               float* out_rgb, RtAux* aux, RtStats* stats) {
   if (!ctx || !ds || !cam || !out_rgb) return RT_E_ABI;
+  if (ds->owner != ctx) return fail(ctx, RT_E_ABI, "scene belongs to another context");
+  if (cam->hsize == 0 || cam->vsize == 0) return fail(ctx, RT_E_ABI, "empty camera");
   auto t0 = std::chrono::steady_clock::now();
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  PartInfo part = make_part(cam, opts);
-  size_t npix = (size_t)part.rows * cam->hsize;
-  float* d_out = nullptr;
-  uint8_t* d_mask = nullptr;
-  int32_t* d_oid = nullptr;
-  float* d_ht = nullptr;
-  int rc = RT_OK;
+  const PartInfo whole = make_part(cam, opts);
+  if (whole.part >= whole.n_parts) return fail(ctx, RT_E_ABI, "part >= n_parts");
+  const size_t npix = (size_t)whole.rows * cam->hsize;
+  const size_t elem[4] = {3 * sizeof(float), 1, sizeof(int32_t), sizeof(float)};
+  void* host[4] = {out_rgb, aux ? (void*)aux->hit_mask : nullptr, aux ? (void*)aux->object_id : nullptr,
+                   aux ? (void*)aux->hit_t : nullptr};
+  for (int k = 0; k < 4; k++) {
+    if (!host[k]) continue;
+    size_t need = (npix ? npix : 1) * elem[k];
+    if (ctx->frame_bytes[k] < need) {
+      if (ctx->d_frame[k]) (void)hipFree(ctx->d_frame[k]);
+      ctx->d_frame[k] = nullptr;
+      ctx->frame_bytes[k] = 0;
+      hipError_t e = hipMalloc(&ctx->d_frame[k], need);
+      if (e != hipSuccess) return fail(ctx, e == hipErrorOutOfMemory ? RT_E_OOM : RT_E_DEVICE, std::string("frame buffer: ") + hipGetErrorString(e));
+      ctx->frame_bytes[k] = need;
+    }
+  }
+  // bands: a full frame splits into contiguous bands of rows (a part with tile_h = band height); a part of a
+  // multi-GPU frame is rendered in one piece
+  PartInfo bands[RT_MAX_BANDS];
+  int nb = 1;
+  bands[0] = whole;
+  if (whole.n_parts == 1 && cam->vsize >= 64) {
+    uint32_t bh = ((cam->vsize + RT_MAX_BANDS - 1) / RT_MAX_BANDS + 7u) & ~7u;
+    nb = (int)((cam->vsize + bh - 1) / bh);
+    for (int b = 0; b < nb; b++)
+      bands[b] = PartInfo{bh, (uint32_t)nb, (uint32_t)b, std::min(bh, cam->vsize - (uint32_t)b * bh)};
+  }
+  Scene sc = ds->sc;
+  sc.flags = opts ? opts->flags : 0;
+  RenderParams rp = make_params(opts);
+  unsigned long long* d_blocks = ctx->d_counters + RT_N_COUNTERS;
+  HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  size_t row0 = 0;
+  for (int b = 0; b < nb; b++) {
+    const size_t p0 = row0 * cam->hsize;
+    RtAux da{host[1] ? (uint8_t*)ctx->d_frame[1] + p0 : nullptr, host[2] ? (int32_t*)ctx->d_frame[2] + p0 : nullptr,
+             host[3] ? (float*)ctx->d_frame[3] + p0 : nullptr};
+    int rc = launch_part(ctx, sc, cam, rp, bands[b], (float*)ctx->d_frame[0] + 3 * p0, aux ? &da : nullptr, ctx->stream,
+                         d_blocks + (size_t)b * RT_N_COUNTERS);
+    if (rc != RT_OK) {
+      (void)hipStreamSynchronize(ctx->stream);
+      return rc;
+    }
+    if (b + 1 == nb) HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_band[b], ctx->stream));
+    row0 += bands[b].rows;
+  }
+  // all bands are queued; now the copies, each as soon as its band is done (a copy to pageable memory keeps the
+  // host busy, so none is issued before the last launch)
+  row0 = 0;
+  for (int b = 0; b < nb; b++) {
+    const size_t p0 = row0 * cam->hsize;
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev_band[b], 0));
+    const size_t n = (size_t)bands[b].rows * cam->hsize;
+    for (int k = 0; k < 4; k++)
+      if (host[k] && n)
+        HIP_TRY(ctx, hipMemcpyAsync((char*)host[k] + p0 * elem[k], (char*)ctx->d_frame[k] + p0 * elem[k], n * elem[k],
+                                    hipMemcpyDeviceToHost, ctx->copy_stream));
+    row0 += bands[b].rows;
+  }
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   RtStats local{};
-  RtAux d_aux{};
-  auto cleanup = [&]() {
-    if (d_out) (void)hipFree(d_out);
-    if (d_mask) (void)hipFree(d_mask);
-    if (d_oid) (void)hipFree(d_oid);
-    if (d_ht) (void)hipFree(d_ht);
-  };
-#define TRY_CLEAN(expr)                                                                      \
-  do {                                                                                       \
-    hipError_t e_ = (expr);                                                                  \
-    if (e_ != hipSuccess) {                                                                  \
-      cleanup();                                                                             \
-      return fail(ctx, e_ == hipErrorOutOfMemory ? RT_E_OOM : RT_E_DEVICE,                   \
-                  std::string(#expr) + ": " + hipGetErrorString(e_));                        \
-    }                                                                                        \
-  } while (0)
-  TRY_CLEAN(hipMalloc((void**)&d_out, (npix ? npix : 1) * 3 * sizeof(float)));
-  if (aux && aux->hit_mask) TRY_CLEAN(hipMalloc((void**)&d_mask, npix ? npix : 1));
-  if (aux && aux->object_id) TRY_CLEAN(hipMalloc((void**)&d_oid, (npix ? npix : 1) * sizeof(int32_t)));
-  if (aux && aux->hit_t) TRY_CLEAN(hipMalloc((void**)&d_ht, (npix ? npix : 1) * sizeof(float)));
-  d_aux.hit_mask = d_mask;
-  d_aux.object_id = d_oid;
-  d_aux.hit_t = d_ht;
-  rc = rt_render_device(ctx, ds, cam, opts, d_out, aux ? &d_aux : nullptr, nullptr, &local);
-  if (rc != RT_OK && rc != RT_E_OVERFLOW) {
-    cleanup();
-    return rc;
-  }
-  TRY_CLEAN(hipMemcpy(out_rgb, d_out, npix * 3 * sizeof(float), hipMemcpyDeviceToHost));
-  if (d_mask) TRY_CLEAN(hipMemcpy(aux->hit_mask, d_mask, npix, hipMemcpyDeviceToHost));
-  if (d_oid) TRY_CLEAN(hipMemcpy(aux->object_id, d_oid, npix * sizeof(int32_t), hipMemcpyDeviceToHost));
-  if (d_ht) TRY_CLEAN(hipMemcpy(aux->hit_t, d_ht, npix * sizeof(float), hipMemcpyDeviceToHost));
-  cleanup();
-#undef TRY_CLEAN
-  if (stats) {
-    *stats = local;
-    stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-  }
-  return rc;
+  double total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  int rc = read_stats(ctx, ctx->stream, &local, total, nb, d_blocks);
+  if (rc != RT_OK) return rc;
+  if (stats) *stats = local;
+  if (local.overflow) return fail(ctx, RT_E_OVERFLOW, "per-ray intersection list overflow");
+  return RT_OK;
 }
 
 int rt_color_at(RtContext* ctx, const RtDeviceScene* ds, const RtRenderOptions* opts, const float* origins,
