@@ -371,15 +371,21 @@ struct XsList {  // every intersection of a ray up to its hit: input of the n1/n
   float t[RT_XS_CAP];
   uint32_t s[RT_XS_CAP];
 };
-// Nine registers: the modes never need their private state at the same time, so it shares fields.
+// Eight registers: the modes never need their private state at the same time, so it shares fields, and the
+// per-intersection decisions (takes / wants / add) are written as selects over those fields rather than as
+// branches on the mode: lanes of a wave are in different modes, and every branch costs exec-mask bookkeeping in the
+// innermost loops.
+//   (t, shape)  closest: best hit so far (inf, -1 if none) | any-shadow: F, the nearest hit on a shadow-less shape
+//               A candidate counts only if it is positive, in front of `bound`, and before (t, shape) in (t, rank) order.
+//   bound       closest: nothing at or beyond it matters (NaN = no bound: t = +inf is a hit the reference shades)
+//               any-shadow: distance to the light, -inf once an occluder is found | collect: keep t <= bound
 struct Sink {
-  float t;       // closest: best t so far (inf if none)
-  int shape;     // closest: its shape (-1 if none)
-  float a;       // closest: u of the best hit          | any-shadow: tF, nearest hit on a shadow-less shape (inf if none)
-  float b;       // closest: v of the best hit
-  int c;         // collect: entries stored (> RT_XS_CAP: the list overflowed) | any-shadow: sF, the shape of tF
+  float t;
+  int shape;
+  float a, b;    // closest: (u, v) of the best hit
+  int c;         // collect: entries stored (> RT_XS_CAP: the list overflowed)
   XsList* xs;    // collect: where the entries go
-  float bound;   // collect: keep t <= bound | any-shadow: distance to the light | closest: nothing at or beyond it matters
+  float bound;
   int mode;
   float lim;     // nothing beyond this t can matter any more (kept up to date by add); -inf: any-shadow found its occluder
   __device__ __forceinline__ void init(int mode_) {
@@ -388,7 +394,7 @@ struct Sink {
     a = b = 0.f;
     c = 0;
     xs = nullptr;
-    bound = __builtin_inff();
+    bound = __builtin_nanf("");
     mode = mode_;
     lim = __builtin_inff();
   }
@@ -410,8 +416,8 @@ struct Sink {
   __device__ __forceinline__ void init_any_shadow(float distance, float tF_, int sF_) {
     init(SINK_ANY_SHADOW);
     bound = distance;
-    a = tF_;
-    c = sF_;
+    t = tF_;
+    shape = sF_;
     lim = __builtin_fminf(distance, tF_);
   }
   __device__ __forceinline__ float u() const { return a; }
@@ -421,15 +427,12 @@ struct Sink {
   __device__ __forceinline__ int overflow() const { return c > RT_XS_CAP ? 1 : 0; }
   // does this traversal look at a shape with these flags at all?
   __device__ __forceinline__ bool takes(uint32_t kind_flags) const {
-    if (mode == SINK_CLOSEST_NOSHADOW) return !(kind_flags & RT_SHAPE_SHADOW);
-    if (mode == SINK_ANY_SHADOW) return (kind_flags & RT_SHAPE_SHADOW) != 0;
-    return true;
+    return (kind_flags & RT_SHAPE_SHADOW) ? mode != SINK_CLOSEST_NOSHADOW : mode != SINK_ANY_SHADOW;
   }
   __device__ __forceinline__ bool wants(float tt, uint32_t s) const {
-    if (mode == SINK_COLLECT) return !of_gt(tt, bound);
-    if (mode == SINK_ANY_SHADOW)
-      return !found() && tt > 0.f && tt < bound && (c < 0 || tt < a || (tt == a && (int)s < c));
-    return tt > 0.f && (shape < 0 || tt < t || (tt == t && (int)s < shape));
+    const bool ordered = tt > 0.f && !(tt >= bound) && (shape < 0 || tt < t || (tt == t && (int)s < shape));
+    const bool listed = !of_gt(tt, bound);
+    return mode == SINK_COLLECT ? listed : ordered;
   }
   __device__ __forceinline__ void add(float tt, uint32_t s, float uu, float vv) {
     if (!wants(tt, s)) return;
@@ -441,14 +444,14 @@ struct Sink {
       } else {
         c = RT_XS_CAP + 1;
       }
-    } else if (mode == SINK_ANY_SHADOW) {
-      lim = -__builtin_inff();
     } else {
-      lim = __builtin_fminf(tt, bound);
-      t = tt;
-      shape = (int)s;
-      a = uu;
-      b = vv;
+      const bool any = mode == SINK_ANY_SHADOW;  // an occluder ends the search; a closest hit replaces the best
+      lim = any ? -__builtin_inff() : __builtin_fminf(tt, bound);
+      bound = any ? -__builtin_inff() : bound;
+      t = any ? t : tt;
+      shape = any ? shape : (int)s;
+      a = any ? a : uu;
+      b = any ? b : vv;
     }
   }
   __device__ __forceinline__ float limit() const { return lim; }
