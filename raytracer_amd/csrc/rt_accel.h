@@ -48,8 +48,9 @@ namespace rtaccel {
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr uint32_t kMinTris = 12;    // subtrees with fewer triangles keep the reference walk
 #ifndef RT_LEAF_TRIS
-#define RT_LEAF_TRIS 7
+#define RT_LEAF_TRIS 9
 #endif
+static_assert(RT_LEAF_TRIS >= 1 && RT_LEAF_TRIS <= 15, "leaf count is a 4-bit field");
 constexpr uint32_t kLeafTris = RT_LEAF_TRIS;    // max triangles per leaf
 constexpr int kMaxDepth = 22;        // device stack holds kMaxDepth + 2 entries
 constexpr float kPadRel = 0.01f;     // static box padding relative to the triangle's largest extent
@@ -450,8 +451,8 @@ inline Result build(const RtScene* s) {
   for (size_t j : todo) {
     if (!outs[j].ok) continue;
     uint64_t nb = r.nodes.size(), tbase = r.tris.size();
-    // references are (index << 3 | count): indices stay below 2^29
-    if (nb + outs[j].nodes.size() + roots.size() >= 0x1FFFFFFFull || tbase + outs[j].tris.size() >= 0x1FFFFFFFull) {
+    // references are (index << 4 | count): indices stay below 2^28, leaves below 16 triangles
+    if (nb + outs[j].nodes.size() + roots.size() >= 0x0FFFFFFFull || tbase + outs[j].tris.size() >= 0x0FFFFFFFull) {
       outs[j].ok = false;
       continue;
     }

@@ -672,12 +672,12 @@ __device__ inline bool aux_intersect(const Scene& sc, uint32_t root_node, uint32
   // entry record: {centre, radius}{lmax, amax, top node, first shape of this instance}; the tree may be shared
   // between instances, so its leaves hold shape and group indices relative to the instance
   const uint32_t shape_base = __float_as_uint(h1.w);
-  uint32_t ref = __float_as_uint(h1.z) << 3;
+  uint32_t ref = __float_as_uint(h1.z) << 4;
   // the computed t of an accepted hit lies within 13u * K * |s| / |d| < 0.55 * pad / |d| of the line's true
   // crossing of the triangle's plane, which is inside the widened box: slack for the t-range pruning
   const float lo0 = sink.wants_negative() ? -__builtin_inff() : 0.f;
   while (true) {
-    uint32_t cnt = ref & 7u, idx = ref >> 3;
+    uint32_t cnt = ref & 15u, idx = ref >> 4;  // reference = index << 4 | leaf triangle count (0: inner node)
     if (cnt == 0u) {
       const float4* N = sc.aux_nodes + 5u * (size_t)idx;
       float4 n0 = N[0], n1 = N[1], n2 = N[2], n3 = N[3];
@@ -714,8 +714,8 @@ __device__ inline bool aux_intersect(const Scene& sc, uint32_t root_node, uint32
       float tl, tr;
       bool hl = aux_box(cur.o, inv, pad, n0, n1, lo, hi, tl);
       bool hr = aux_box(cur.o, inv, pad, n2, n3, lo, hi, tr);
-      uint32_t rl = (__float_as_uint(n0.w) << 3) | __float_as_uint(n1.w);
-      uint32_t rr = (__float_as_uint(n2.w) << 3) | __float_as_uint(n3.w);
+      uint32_t rl = (__float_as_uint(n0.w) << 4) | __float_as_uint(n1.w);
+      uint32_t rr = (__float_as_uint(n2.w) << 4) | __float_as_uint(n3.w);
       if (hl && hr) {
         bool left_first = !(tr < tl);
         ref = left_first ? rl : rr;

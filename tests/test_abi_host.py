@@ -159,7 +159,7 @@ def test_aux_bvh_is_well_formed(obj_files):
                 if cnt == 0:
                     stack.append((ref, depth + 1, mn, mx))
                     continue
-                assert 1 <= cnt <= 7
+                assert 1 <= cnt <= 15
                 for t in at[ref:ref + cnt]:
                     si, owner = shape_base + int(t["shape"]), R + int(t["owner"])  # leaves are instance-relative
                     covered[si] += 1
