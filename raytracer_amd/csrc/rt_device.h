@@ -113,6 +113,21 @@ struct Scene {
   uint32_t props;  // RT_SCENE_* (derived by rt_scene_create)
 };
 
+// The scene tables are never written while a kernel runs.  Reading them through the constant address space tells the
+// compiler so: a load whose address is wave-uniform then becomes a scalar load (SGPRs, off the vector-memory path)
+// even though the persistent kernel stores pixels between traversals, which otherwise makes every earlier-proven
+// "not clobbered" load a per-lane vector load (16 VGPRs for one group record).
+#define RT_CONST_AS __attribute__((address_space(4)))
+template <class T>
+__device__ __forceinline__ const T RT_CONST_AS* cst(const T* p) {
+  return (const T RT_CONST_AS*)(uintptr_t)p;
+}
+typedef float f4n __attribute__((ext_vector_type(4)));     // native vectors: HIP's float4 / uint4 classes cannot be
+typedef uint32_t u4n __attribute__((ext_vector_type(4)));  // copied out of another address space
+struct M34 {  // rows 0..2 of an inverse transform, fetched as three 16-B loads
+  f4n r0, r1, r2;
+};
+__device__ __forceinline__ M34 load_xform(const Scene& sc, uint32_t xform);
 // Matrix<4,4> * Point / Vector (matrices.rs:68-80, :220-236): row sums left to right.
 __device__ __forceinline__ V3 xf_point(const float* m, V3 p) {
   return V3{((m[0] * p.x + m[1] * p.y) + m[2] * p.z) + m[3], ((m[4] * p.x + m[5] * p.y) + m[6] * p.z) + m[7],
@@ -127,9 +142,17 @@ __device__ __forceinline__ V3 xf_normal(const float* m, V3 n) {
   return V3{(m[0] * n.x + m[4] * n.y) + m[8] * n.z, (m[1] * n.x + m[5] * n.y) + m[9] * n.z,
             (m[2] * n.x + m[6] * n.y) + m[10] * n.z};
 }
+__device__ __forceinline__ M34 load_xform(const Scene& sc, uint32_t xform) {
+  const f4n RT_CONST_AS* q = cst(reinterpret_cast<const f4n*>(sc.xforms + xform));
+  return M34{q[0], q[1], q[2]};
+}
 __device__ __forceinline__ Ray xf_ray(const Scene& sc, uint32_t xform, Ray r) {  // rays.rs:19-24
-  const float* m = sc.xforms[xform].m;
-  return Ray{xf_point(m, r.o), xf_vector(m, r.d)};
+  const M34 m = load_xform(sc, xform);
+  return Ray{V3{((m.r0.x * r.o.x + m.r0.y * r.o.y) + m.r0.z * r.o.z) + m.r0.w,
+                ((m.r1.x * r.o.x + m.r1.y * r.o.y) + m.r1.z * r.o.z) + m.r1.w,
+                ((m.r2.x * r.o.x + m.r2.y * r.o.y) + m.r2.z * r.o.z) + m.r2.w},
+             V3{(m.r0.x * r.d.x + m.r0.y * r.d.y) + m.r0.z * r.d.z, (m.r1.x * r.d.x + m.r1.y * r.d.y) + m.r1.z * r.d.z,
+                (m.r2.x * r.d.x + m.r2.y * r.d.y) + m.r2.z * r.d.z}};
 }
 
 // Cube::check_axis (shapes/cube.rs:67-85)
@@ -462,8 +485,8 @@ struct Sink {
 // Shape::intersect (shapes.rs:204-246): inverse-transform the ray, dispatch on kind.
 template <class Sink>
 __device__ __forceinline__ void shape_intersect(const Scene& sc, uint32_t si, const Ray& ray, Sink& sink) {
-  const uint4* raw = reinterpret_cast<const uint4*>(sc.shapes + si);
-  uint4 w0 = raw[0], w1 = raw[1];
+  const u4n RT_CONST_AS* raw = cst(reinterpret_cast<const u4n*>(sc.shapes + si));
+  u4n w0 = raw[0], w1 = raw[1];
   uint32_t kf = w0.x, xform = w0.y, prim = w1.y;
   if (!sink.takes(kf)) return;
   float mn = __uint_as_float(w1.z), mx = __uint_as_float(w1.w);
@@ -805,9 +828,9 @@ __device__ RT_WI_INLINE void world_intersect(const Scene& sc, const Ray& ray, Si
     uint32_t i = 0;                   // wave-uniform
     while (i < sc.n_nodes) {
       i = __builtin_amdgcn_readfirstlane(i);
-      const uint4* raw = reinterpret_cast<const uint4*>(sc.nodes + i);
+      const u4n RT_CONST_AS* raw = cst(reinterpret_cast<const u4n*>(sc.nodes + i));
       RT_T0(tl);
-      uint4 w0 = raw[0], w1 = raw[1], w2 = raw[2], w3 = raw[3];
+      u4n w0 = raw[0], w1 = raw[1], w2 = raw[2], w3 = raw[3];
 #ifdef RT_PHASE_TIMERS
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       RT_TACC(t_load, tl);
