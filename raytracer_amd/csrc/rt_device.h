@@ -129,16 +129,19 @@ struct M34 {  // rows 0..2 of an inverse transform, fetched as three 16-B loads
 };
 __device__ __forceinline__ M34 load_xform(const Scene& sc, uint32_t xform);
 // Matrix<4,4> * Point / Vector (matrices.rs:68-80, :220-236): row sums left to right.
-__device__ __forceinline__ V3 xf_point(const float* m, V3 p) {
+template <class P>
+__device__ __forceinline__ V3 xf_point(P m, V3 p) {
   return V3{((m[0] * p.x + m[1] * p.y) + m[2] * p.z) + m[3], ((m[4] * p.x + m[5] * p.y) + m[6] * p.z) + m[7],
             ((m[8] * p.x + m[9] * p.y) + m[10] * p.z) + m[11]};
 }
-__device__ __forceinline__ V3 xf_vector(const float* m, V3 v) {
+template <class P>
+__device__ __forceinline__ V3 xf_vector(P m, V3 v) {
   return V3{(m[0] * v.x + m[1] * v.y) + m[2] * v.z, (m[4] * v.x + m[5] * v.y) + m[6] * v.z,
             (m[8] * v.x + m[9] * v.y) + m[10] * v.z};
 }
 // inverse.transpose() * normal (shapes.rs:281-285): column sums of the 3x3 block.
-__device__ __forceinline__ V3 xf_normal(const float* m, V3 n) {
+template <class P>
+__device__ __forceinline__ V3 xf_normal(P m, V3 n) {
   return V3{(m[0] * n.x + m[4] * n.y) + m[8] * n.z, (m[1] * n.x + m[5] * n.y) + m[9] * n.z,
             (m[2] * n.x + m[6] * n.y) + m[10] * n.z};
 }
@@ -375,8 +378,8 @@ __device__ __forceinline__ bool isect_triangle(const Ray& r, V3 p1, V3 e1, V3 e2
   return true;
 }
 __device__ __forceinline__ void load_tri(const Scene& sc, uint32_t prim, V3& p1, V3& e1, V3& e2) {
-  const float4* g = sc.tri_geom + 3u * (size_t)prim;
-  float4 a = g[0], b = g[1], c = g[2];
+  const f4n RT_CONST_AS* g = cst(reinterpret_cast<const f4n*>(sc.tri_geom)) + 3u * (size_t)prim;
+  f4n a = g[0], b = g[1], c = g[2];
   p1 = v3(a.x, a.y, a.z);
   e1 = v3(b.x, b.y, b.z);
   e2 = v3(c.x, c.y, c.z);
@@ -539,7 +542,7 @@ __device__ __forceinline__ bool entry_less(float ta, uint32_t sa, float tb, uint
 __device__ inline int dedup_sorted(const Scene& sc, float* t, uint32_t* s, int lo, int hi) {
   int w = lo;
   for (int i = lo; i < hi; i++) {
-    if (i + 1 < hi && of_eq(t[i], t[i + 1]) && vclass_eq(sc.shapes[s[i]].vclass, sc.shapes[s[i + 1]].vclass)) continue;
+    if (i + 1 < hi && of_eq(t[i], t[i + 1]) && vclass_eq(cst(sc.shapes)[s[i]].vclass, cst(sc.shapes)[s[i + 1]].vclass)) continue;
     t[w] = t[i];
     s[w] = s[i];
     w++;
@@ -571,8 +574,8 @@ __device__ inline void csg_eval(const Scene& sc, RtCsgRoot root, const Ray& ray,
   int sp = 0;
   L.n = 0;
   for (uint32_t k = root.first; k < root.first + root.count; k++) {
-    const uint4* raw = reinterpret_cast<const uint4*>(sc.csg_nodes + k);
-    uint4 w0 = raw[0], w1 = raw[1], w2 = raw[2];
+    const u4n RT_CONST_AS* raw = cst(reinterpret_cast<const u4n*>(sc.csg_nodes + k));
+    u4n w0 = raw[0], w1 = raw[1], w2 = raw[2];
     uint32_t op = w0.w, flags = w1.w;
     int nseg = ((flags & RT_CSG_LEFT_IS_SHAPE) ? 0 : 1) + ((flags & RT_CSG_RIGHT_IS_SHAPE) ? 0 : 1);
     int start = nseg ? seg[sp - nseg] : L.n;
@@ -595,13 +598,13 @@ __device__ inline void csg_eval(const Scene& sc, RtCsgRoot root, const Ray& ray,
     uint32_t left_lo = w2.z, left_hi = w2.w;
     for (int i = start; i < L.n; i++) {
       uint32_t s = L.s[i];
-      uint32_t vc = sc.shapes[s].vclass;
+      uint32_t vc = cst(sc.shapes)[s].vclass;
       bool l_hit;
       if (flags & RT_CSG_LEFT_IS_SHAPE) {
-        l_hit = vclass_eq(sc.shapes[w2.x].vclass, vc);
+        l_hit = vclass_eq(cst(sc.shapes)[w2.x].vclass, vc);
       } else {  // Csg::includes (csg.rs:74-85): by value over the left subtree's leaves
         l_hit = false;
-        for (uint32_t q = left_lo; q < left_hi && !l_hit; q++) l_hit = vclass_eq(sc.shapes[q].vclass, vc);
+        for (uint32_t q = left_lo; q < left_hi && !l_hit; q++) l_hit = vclass_eq(cst(sc.shapes)[q].vclass, vc);
       }
       if (csg_allowed(op, l_hit, in_l, in_r)) {
         L.t[w] = L.t[i];
@@ -630,7 +633,7 @@ __device__ __forceinline__ uint32_t* aux_stack() {
 }
 // Conservative slab test against a box widened by `pad`: never reports a miss for a line that comes
 // within the padding of the box contents; NaNs (0 * inf) count as "inside".
-__device__ __forceinline__ bool aux_box(V3 o, V3 inv, float pad, float4 mn, float4 mx, float lo, float hi,
+__device__ __forceinline__ bool aux_box(V3 o, V3 inv, float pad, f4n mn, f4n mx, float lo, float hi,
                                         float& tnear) {
   float ax = ((mn.x - pad) - o.x) * inv.x, bx = ((mx.x + pad) - o.x) * inv.x;
   float ay = ((mn.y - pad) - o.y) * inv.y, by = ((mx.y + pad) - o.y) * inv.y;
@@ -649,8 +652,8 @@ __device__ __forceinline__ bool aux_box(V3 o, V3 inv, float pad, float4 mn, floa
 template <bool COUNT>
 __device__ __forceinline__ bool aux_gate(const Scene& sc, uint32_t g, uint32_t root, const Ray& cur, Counters& cn) {
   while (g != root && g != RT_AUX_NONE) {
-    const uint4* raw = reinterpret_cast<const uint4*>(sc.nodes + g);
-    uint4 w0 = raw[0], w1 = raw[1], w3 = raw[3];
+    const u4n RT_CONST_AS* raw = cst(reinterpret_cast<const u4n*>(sc.nodes + g));
+    u4n w0 = raw[0], w1 = raw[1], w3 = raw[3];
     if (COUNT) cn.node_visits++;
     float tmin, tmax;
     V3 bmin = v3(__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z));
@@ -667,8 +670,8 @@ __device__ inline bool aux_intersect(const Scene& sc, uint32_t root_node, uint32
   // the nesting argument behind aux_gate needs one axis on the non-parallel branch of check_axis
   if (!(__builtin_fabsf(cur.d.x) >= 1e-4f || __builtin_fabsf(cur.d.y) >= 1e-4f || __builtin_fabsf(cur.d.z) >= 1e-4f))
     return false;
-  const float4* A = sc.aux_nodes + 5u * (size_t)aux_root;
-  float4 h0 = A[0], h1 = A[1];
+  const f4n RT_CONST_AS* A = cst(reinterpret_cast<const f4n*>(sc.aux_nodes)) + 5u * (size_t)aux_root;
+  f4n h0 = A[0], h1 = A[1];
   // Ray-dependent widening (DESIGN.md "Auxiliary BVH"): in f32 the reference's triangle test accepts a
   // line that passes the triangle's plane up to 16u * K * (|s| + L) outside it (u = 2^-24,
   // K = |e1||e2||d| / |det| <= 1e4 * |e1||e2||d| because |det| >= 1e-4 for every accepted hit, |s| = distance
@@ -702,12 +705,12 @@ __device__ inline bool aux_intersect(const Scene& sc, uint32_t root_node, uint32
   while (true) {
     uint32_t cnt = ref & 15u, idx = ref >> 4;  // reference = index << 4 | leaf triangle count (0: inner node)
     if (cnt == 0u) {
-      const float4* N = sc.aux_nodes + 5u * (size_t)idx;
-      float4 n0 = N[0], n1 = N[1], n2 = N[2], n3 = N[3];
+      const f4n RT_CONST_AS* N = cst(reinterpret_cast<const f4n*>(sc.aux_nodes)) + 5u * (size_t)idx;
+      f4n n0 = N[0], n1 = N[1], n2 = N[2], n3 = N[3];
       RT_UTIL(0);
       if (COUNT) cn.aux_tests += 2;
       float kb = kmax;
-      float4 n4 = make_float4(0.f, 0.f, 0.f, -2.f);
+      f4n n4 = f4n{0.f, 0.f, 0.f, -2.f};
       if (use_cone) n4 = N[4];
 #ifndef RT_CONE_MODE
 #define RT_CONE_MODE 2
@@ -753,9 +756,9 @@ __device__ inline bool aux_intersect(const Scene& sc, uint32_t root_node, uint32
     } else {
       if (COUNT) cn.tri_tests += cnt;
       RT_UTIL(1);
-      const float4* T = sc.aux_tris + 3u * (size_t)idx;
+      const f4n RT_CONST_AS* T = cst(reinterpret_cast<const f4n*>(sc.aux_tris)) + 3u * (size_t)idx;
       for (uint32_t k = 0; k < cnt; k++) {
-        float4 a = T[3 * k], b = T[3 * k + 1], c = T[3 * k + 2];
+        f4n a = T[3 * k], b = T[3 * k + 1], c = T[3 * k + 2];
         float t, u, v;
         if (sink.takes(__float_as_uint(c.w)) &&
             isect_triangle(cur, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), v3(c.x, c.y, c.z), t, u, v)) {
@@ -786,11 +789,11 @@ __device__ inline Ray ray_in_space_of(const Scene& sc, int xf_node, const Ray& w
   int q = xf_node;
   while (q >= 0 && n < RT_MAX_XF_DEPTH) {
     chain[n++] = q;
-    int par = sc.nodes[q].parent;
-    q = par >= 0 ? sc.nodes[par].next_xf : -1;
+    int par = cst(sc.nodes)[q].parent;
+    q = par >= 0 ? cst(sc.nodes)[par].next_xf : -1;
   }
   Ray r = world;
-  for (int k = n - 1; k >= 0; k--) r = xf_ray(sc, sc.nodes[chain[k]].xform, r);
+  for (int k = n - 1; k >= 0; k--) r = xf_ray(sc, cst(sc.nodes)[chain[k]].xform, r);
   return r;
 }
 // The walk is WAVE-SYNCHRONOUS: every lane walks the same DFS order and lanes differ only in the
@@ -815,7 +818,7 @@ __device__ RT_WI_INLINE void world_intersect(const Scene& sc, const Ray& ray, Si
     for (uint32_t c = 0; c < sc.n_csg_roots; c++) {
       csg_eval(sc, sc.csg_roots[c], ray, L);
       for (int i = 0; i < L.n; i++)
-        if (sink.takes(sc.shapes[L.s[i]].kind_flags)) sink.add(L.t[i], L.s[i], __builtin_nanf(""), __builtin_nanf(""));
+        if (sink.takes(cst(sc.shapes)[L.s[i]].kind_flags)) sink.add(L.t[i], L.s[i], __builtin_nanf(""), __builtin_nanf(""));
     }
     cn.overflow += L.overflow;
   }
@@ -845,9 +848,9 @@ __device__ RT_WI_INLINE void world_intersect(const Scene& sc, const Ray& ray, Si
       if (my_i == i) {
         if (i >= leave_at) {
           int par = (int)w2.w;
-          int q = par >= 0 ? sc.nodes[par].next_xf : -1;
+          int q = par >= 0 ? cst(sc.nodes)[par].next_xf : -1;
           cur = q >= 0 ? ray_in_space_of(sc, q, ray) : ray;
-          leave_at = q >= 0 ? sc.nodes[q].skip : 0xFFFFFFFFu;
+          leave_at = q >= 0 ? cst(sc.nodes)[q].skip : 0xFFFFFFFFu;
         }
         if (COUNT) cn.node_visits++;
         RT_UTIL(2);
@@ -883,7 +886,7 @@ __device__ RT_WI_INLINE void world_intersect(const Scene& sc, const Ray& ray, Si
             V3 p1, e1, e2;
             load_tri(sc, w3.x + k, p1, e1, e2);
             float t, u, v;
-            if (descend && sink.takes(sc.shapes[first_shape + k].kind_flags) && isect_triangle(cur, p1, e1, e2, t, u, v))
+            if (descend && sink.takes(cst(sc.shapes)[first_shape + k].kind_flags) && isect_triangle(cur, p1, e1, e2, t, u, v))
               sink.add(t, first_shape + k, u, v);
           }
         } else {
@@ -920,13 +923,13 @@ __device__ inline V3 world_to_object(const Scene& sc, uint32_t shape_xform, int 
   int n = 0;
   int g = parent;
   while (g >= 0) {
-    int q = sc.nodes[g].next_xf;
+    int q = cst(sc.nodes)[g].next_xf;
     if (q < 0) break;
     if (n < RT_MAX_XF_DEPTH) chain[n++] = q;
-    g = sc.nodes[q].parent;
+    g = cst(sc.nodes)[q].parent;
   }
-  for (int i = n - 1; i >= 0; i--) p = xf_point(sc.xforms[sc.nodes[chain[i]].xform].m, p);
-  if (shape_xform) p = xf_point(sc.xforms[shape_xform].m, p);
+  for (int i = n - 1; i >= 0; i--) p = xf_point(cst(sc.xforms)[cst(sc.nodes)[chain[i]].xform].m, p);
+  if (shape_xform) p = xf_point(cst(sc.xforms)[shape_xform].m, p);
   return p;
 }
 __device__ __forceinline__ V3 renorm_identity(V3 n, uint32_t levels) {
@@ -940,17 +943,17 @@ __device__ __forceinline__ V3 renorm_identity(V3 n, uint32_t levels) {
 }
 __device__ inline V3 normal_to_world(const Scene& sc, uint32_t shape_xform, int parent, V3 n) {
   if (shape_xform)
-    n = normalize(xf_normal(sc.xforms[shape_xform].m, n));
+    n = normalize(xf_normal(cst(sc.xforms)[shape_xform].m, n));
   else
     n = normalize(n);
   int g = parent;
   while (g >= 0) {
-    const RtNode& nd = sc.nodes[g];
+    const RtNode RT_CONST_AS& nd = cst(sc.nodes)[g];
     n = renorm_identity(n, nd.idrun);
     int q = nd.next_xf;
     if (q < 0) break;
-    n = normalize(xf_normal(sc.xforms[sc.nodes[q].xform].m, n));
-    g = sc.nodes[q].parent;
+    n = normalize(xf_normal(cst(sc.xforms)[cst(sc.nodes)[q].xform].m, n));
+    g = cst(sc.nodes)[q].parent;
   }
   return n;
 }
@@ -981,12 +984,12 @@ __device__ inline V3 local_normal_at(const Scene& sc, uint32_t kf, float mn, flo
       return v3(lp.x, y, lp.z);
     }
     case RT_TRIANGLE: {  // triangle.rs:89-91
-      float4 a = sc.tri_normals[3u * (size_t)prim];
+      f4n a = cst(reinterpret_cast<const f4n*>(sc.tri_normals))[3u * (size_t)prim];
       return v3(a.x, a.y, a.z);
     }
     default: {  // smooth_triangle.rs:92-94
-      const float4* g = sc.tri_normals + 3u * (size_t)prim;
-      float4 a = g[0], b = g[1], c = g[2];
+      const f4n RT_CONST_AS* g = cst(reinterpret_cast<const f4n*>(sc.tri_normals)) + 3u * (size_t)prim;
+      f4n a = g[0], b = g[1], c = g[2];
       V3 n1 = v3(a.x, a.y, a.z), n2 = v3(b.x, b.y, b.z), n3 = v3(c.x, c.y, c.z);
       return (hu * n2 + hv * n3) + (1.f - hu - hv) * n1;
     }
@@ -1140,7 +1143,7 @@ struct Hit {
   int shape;
 };
 
-__device__ __forceinline__ V3 point_on_light(const RtLight& l, uint32_t li, uint32_t u, uint32_t v, uint32_t site,
+__device__ __forceinline__ V3 point_on_light(const RtLight RT_CONST_AS& l, uint32_t li, uint32_t u, uint32_t v, uint32_t site,
                                              const RenderParams& rp, uint32_t pixel, uint32_t path) {
   float ju, jv;
   if (rp.jitter_mode == RT_JITTER_COUNTER) {
@@ -1202,16 +1205,16 @@ __device__ inline void refractive_indices(const Scene& sc, float* ts, uint32_t* 
   n2 = 1.f;
   uint32_t containers[RT_XS_CAP];
   int nc = 0;
-  uint32_t hit_vc = sc.shapes[hit_shape].vclass;
+  uint32_t hit_vc = cst(sc.shapes)[hit_shape].vclass;
   for (int i = 0; i < n; i++) {
     uint32_t s = ss[i];
-    uint32_t vc = sc.shapes[s].vclass;
+    uint32_t vc = cst(sc.shapes)[s].vclass;
     // `x == &intersection`: same t, equal shape value (u,v are functions of ray and shape value)
     bool is_hit = of_eq(ts[i], hit_t) && vclass_eq(vc, hit_vc);
-    if (is_hit && nc > 0) n1 = sc.materials[sc.shapes[containers[nc - 1]].material].refractive_index;
+    if (is_hit && nc > 0) n1 = cst(sc.materials)[cst(sc.shapes)[containers[nc - 1]].material].refractive_index;
     int pos = -1;
     for (int k = 0; k < nc; k++)
-      if (vclass_eq(sc.shapes[containers[k]].vclass, vc)) {
+      if (vclass_eq(cst(sc.shapes)[containers[k]].vclass, vc)) {
         pos = k;
         break;
       }
@@ -1221,7 +1224,7 @@ __device__ inline void refractive_indices(const Scene& sc, float* ts, uint32_t* 
     } else {
       containers[nc++] = s;
     }
-    if (is_hit && nc > 0) n2 = sc.materials[sc.shapes[containers[nc - 1]].material].refractive_index;
+    if (is_hit && nc > 0) n2 = cst(sc.materials)[cst(sc.shapes)[containers[nc - 1]].material].refractive_index;
   }
 }
 
@@ -1377,8 +1380,8 @@ __device__ inline void integrate(const Scene& sc, const RenderParams& rp, const 
         if (COUNT) cn.shaded++;
         // ---- Computations::prepare (intersections.rs:121-139) ----
         const Ray sray{pk_ld3(pk, PK_SRAY_O), pk_ld3(pk, PK_SRAY_D)};
-        const uint4* raw = reinterpret_cast<const uint4*>(sc.shapes + hit.shape);
-        uint4 w0 = raw[0], w1 = raw[1];
+        const u4n RT_CONST_AS* raw = cst(reinterpret_cast<const u4n*>(sc.shapes + hit.shape));
+        u4n w0 = raw[0], w1 = raw[1];
         uint32_t kf = w0.x, sxf = w0.y, prim = w1.y;
         mat_id = w0.z;
         int parent = (int)w0.w;
@@ -1399,12 +1402,12 @@ __device__ inline void integrate(const Scene& sc, const RenderParams& rp, const 
         normalv = normal_to_world(sc, sxf, parent, ln);
         if (dot(normalv, eyev) < 0.f) normalv = -normalv;
         V3 over_point = point + 1e-4f * normalv;
-        const RtMaterial& m = sc.materials[mat_id];
+        const RtMaterial RT_CONST_AS& m = cst(sc.materials)[mat_id];
         V3 mcolor;
         if (m.pattern >= 0) {  // pattern_at_shape at over_point (patterns.rs:79-91, world.rs:72)
           const RtPattern& pat = sc.patterns[m.pattern];
           V3 op = world_to_object(sc, sxf, parent, over_point);
-          V3 pp = xf_point(sc.xforms[pat.xform].m, op);
+          V3 pp = xf_point(cst(sc.xforms)[pat.xform].m, op);
           mcolor = pattern_at(sc, pat, pp);
         } else {
           mcolor = v3(m.color[0], m.color[1], m.color[2]);
@@ -1426,9 +1429,9 @@ __device__ inline void integrate(const Scene& sc, const RenderParams& rp, const 
       // World::is_shadowed (world.rs:101-111): closest-hit semantics, see Sink::init_any_shadow
       bool shadowed = sink.mode == SINK_ANY_SHADOW
                           ? sink.found()
-                          : (sink.shape >= 0 && sink.t < distance && (sc.shapes[sink.shape].kind_flags & RT_SHAPE_SHADOW));
-      const RtLight& L = sc.lights[li];
-      const RtMaterial& m = sc.materials[mat_id];
+                          : (sink.shape >= 0 && sink.t < distance && (cst(sc.shapes)[sink.shape].kind_flags & RT_SHAPE_SHADOW));
+      const RtLight RT_CONST_AS& L = cst(sc.lights)[li];
+      const RtMaterial RT_CONST_AS& m = cst(sc.materials)[mat_id];
       const float m_ambient = m.ambient, m_diffuse = m.diffuse, m_specular = m.specular, m_shininess = m.shininess;
       const Ray sray{pk_ld3(pk, PK_SRAY_O), pk_ld3(pk, PK_SRAY_D)};
       const V3 eyev = -sray.d;
@@ -1486,7 +1489,7 @@ __device__ inline void integrate(const Scene& sc, const RenderParams& rp, const 
     while (st != ST_TRACE && st != ST_DONE && st != ST_IDLE) {
       if (st == ST_NEXT_LIGHT) {
         if (li < sc.n_lights) {
-          const RtLight& L = sc.lights[li];
+          const RtLight RT_CONST_AS& L = cst(sc.lights)[li];
           V3 lpos;
           if (L.kind == RT_LIGHT_POINT) {
             lpos = v3(L.position[0], L.position[1], L.position[2]);
@@ -1509,7 +1512,7 @@ __device__ inline void integrate(const Scene& sc, const RenderParams& rp, const 
       } else if (st == ST_LIGHTS_DONE) {
         pk_st3(pk, PK_RESULT, pk_ld3(pk, PK_RESULT) + pk_ld(pk, PK_WEIGHT) * pk_ld3(pk, PK_SURFACE));
         // ---- secondary rays (world.rs:78-86, :113-148); once per light in the reference (Q4) ----
-        const RtMaterial& m = sc.materials[mat_id];
+        const RtMaterial RT_CONST_AS& m = cst(sc.materials)[mat_id];
         bool want_reflect = m.reflective != 0.f, want_refract = m.transparency != 0.f;
         if (remaining == 0 || sc.n_lights == 0 || (!want_reflect && !want_refract)) {
           st = ST_NEXT_RAY;
@@ -1523,7 +1526,7 @@ __device__ inline void integrate(const Scene& sc, const RenderParams& rp, const 
           st = ST_SECONDARY;
         }
       } else if (st == ST_SECONDARY) {
-        const RtMaterial& m = sc.materials[mat_id];
+        const RtMaterial RT_CONST_AS& m = cst(sc.materials)[mat_id];
         const float m_reflective = m.reflective, m_transparency = m.transparency;
         const Ray sray{pk_ld3(pk, PK_SRAY_O), pk_ld3(pk, PK_SRAY_D)};
         const float weight = pk_ld(pk, PK_WEIGHT);
@@ -1620,7 +1623,7 @@ __device__ __forceinline__ void simple_intersect(const Scene& sc, const Ray& ray
     for (uint32_t c = 0; c < sc.n_csg_roots; c++) {
       csg_eval(sc, sc.csg_roots[c], ray, L);
       for (int i = 0; i < L.n; i++)
-        if (sink.takes(sc.shapes[L.s[i]].kind_flags)) sink.add(L.t[i], L.s[i], __builtin_nanf(""), __builtin_nanf(""));
+        if (sink.takes(cst(sc.shapes)[L.s[i]].kind_flags)) sink.add(L.t[i], L.s[i], __builtin_nanf(""), __builtin_nanf(""));
     }
     cn.overflow += L.overflow;
   }
@@ -1647,7 +1650,7 @@ __device__ __forceinline__ bool direct_is_shadowed(const Scene& sc, V3 light_pos
     sink.init_closest();
     sink.set_cap(distance);
     simple_intersect<COUNT>(sc, Ray{p, direction}, sink, cn);
-    return sink.shape >= 0 && sink.t < distance && (sc.shapes[sink.shape].kind_flags & RT_SHAPE_SHADOW);
+    return sink.shape >= 0 && sink.t < distance && (cst(sc.shapes)[sink.shape].kind_flags & RT_SHAPE_SHADOW);
   }
   sink.init_any_shadow(distance, __builtin_inff(), -1);
   simple_intersect<COUNT>(sc, Ray{p, direction}, sink, cn);
@@ -1674,8 +1677,8 @@ __device__ __forceinline__ V3 color_at_direct(const Scene& sc, const RenderParam
     if (hit.shape < 0) continue;
     if (COUNT) cn.shaded++;
     // ---- Computations::prepare (intersections.rs:121-139) ----
-    const uint4* raw = reinterpret_cast<const uint4*>(sc.shapes + hit.shape);
-    uint4 w0 = raw[0], w1 = raw[1];
+    const u4n RT_CONST_AS* raw = cst(reinterpret_cast<const u4n*>(sc.shapes + hit.shape));
+    u4n w0 = raw[0], w1 = raw[1];
     uint32_t kf = w0.x, sxf = w0.y, mat_id = w0.z, prim = w1.y;
     int parent = (int)w0.w;
     float smn = __uint_as_float(w1.z), smx = __uint_as_float(w1.w);
@@ -1698,14 +1701,14 @@ __device__ __forceinline__ V3 color_at_direct(const Scene& sc, const RenderParam
     V3 over_point = point + 1e-4f * normalv;
     V3 under_point = point - 1e-4f * normalv;
 
-    const RtMaterial& m = sc.materials[mat_id];
+    const RtMaterial RT_CONST_AS& m = cst(sc.materials)[mat_id];
     const float m_ambient = m.ambient, m_diffuse = m.diffuse, m_specular = m.specular, m_shininess = m.shininess;
     const float m_reflective = m.reflective, m_transparency = m.transparency;
     V3 mcolor;
     if (m.pattern >= 0) {  // pattern_at_shape at over_point (patterns.rs:79-91, world.rs:72)
       const RtPattern& pat = sc.patterns[m.pattern];
       V3 op = world_to_object(sc, sxf, parent, over_point);
-      V3 pp = xf_point(sc.xforms[pat.xform].m, op);
+      V3 pp = xf_point(cst(sc.xforms)[pat.xform].m, op);
       mcolor = pattern_at(sc, pat, pp);
     } else {
       mcolor = v3(m.color[0], m.color[1], m.color[2]);
@@ -1714,7 +1717,7 @@ __device__ __forceinline__ V3 color_at_direct(const Scene& sc, const RenderParam
     // ---- World::shade_hit (world.rs:64-89): direct lighting, summed over lights ----
     V3 surface_sum = v3(0.f, 0.f, 0.f);
     for (uint32_t li = 0; li < sc.n_lights; li++) {
-      const RtLight& L = sc.lights[li];
+      const RtLight RT_CONST_AS& L = cst(sc.lights)[li];
       V3 lcol = v3(L.intensity[0], L.intensity[1], L.intensity[2]);
       V3 effective = mulc(mcolor, lcol);
       V3 ambient = m_ambient * effective;
