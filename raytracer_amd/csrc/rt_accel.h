@@ -495,4 +495,113 @@ inline Result build(const RtScene* s) {
 }
 
 
+// ---------------------------------------------------------------------------------------------------------
+// Cull spheres for bounded analytic shapes (cubes, spheres).  The reference tests every ray against every shape
+// of a group / of the world: ray into object space (shapes.rs:204-246), then the local test.  Before that the kernel
+// tests the ray, in the space it is in, against a sphere around the shape; a miss skips the transform and the test.
+// A ray the sphere test rejects must be one the reference's own f32 test rejects:
+//  * cube (cube.rs:67-114): an axis with |d| < 1e-4 is treated as parallel, which lets the accepted line drift by up to
+//    1e-4 |t| on that axis, |t| <= sqrt(3) (|o - c| + r) / |d| at the box (bounded through the largest direction
+//    component, which is never "parallel" unless all are, and then the test only asks whether the origin is inside).
+//    In the outer space, A = linear part of the inverse transform: drift |d| <= sqrt(3) 1e-4 |A^-1|^2 (|A| |o-c| + r_l).
+//  * sphere (sphere.rs:64-80): disc = b^2 - 4ac = 4a (1 - rho^2), rho = distance of the local line from the origin;
+//    its f32 evaluation errs by < 32 u a |o'|^2 (u = 2^-24), so the sign is certain for rho^2 > 1 + 2e-6 |o'|^2;
+//    |o'| <= |A| |o - c|.
+//  * rounding of the f32 transform itself: below 2e-6 |A^-1| (|A| (|o - c| + |c|) + |t| + r_l).
+// The kernel rejects when  |(c - o) x d| > |d| (R + q1 |o-c| + q0 + kq |o-c|^2) + k1 |o-c| + k0  (times 1 + 1e-4),
+// R = radius of the shape's image (farthest cube corner; largest singular value of A^-1 for the sphere), the
+// coefficients below with Frobenius norms as upper bounds and factors of 2-5 to spare.  Non-finite => never rejected.
+// 12 floats per record: {c.xyz, R} {q1, q0, kq, k1} {k0, 0, 0, 0}.
+// ---------------------------------------------------------------------------------------------------------
+inline double sym3_max_eig(double m[3][3]) {  // Jacobi rotations on a symmetric 3x3
+  double a[3][3];
+  std::memcpy(a, m, sizeof(a));
+  for (int sweep = 0; sweep < 32; sweep++) {
+    double off = std::fabs(a[0][1]) + std::fabs(a[0][2]) + std::fabs(a[1][2]);
+    if (off < 1e-300) break;
+    for (int p = 0; p < 2; p++)
+      for (int q = p + 1; q < 3; q++) {
+        if (std::fabs(a[p][q]) < 1e-300) continue;
+        double th = 0.5 * std::atan2(2.0 * a[p][q], a[q][q] - a[p][p]);
+        double c = std::cos(th), sn = std::sin(th);
+        double r[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+        r[p][p] = c, r[q][q] = c, r[p][q] = sn, r[q][p] = -sn;
+        double t[3][3] = {}, u[3][3] = {};
+        for (int i = 0; i < 3; i++)
+          for (int j = 0; j < 3; j++)
+            for (int k = 0; k < 3; k++) t[i][j] += r[k][i] * a[k][j];  // R^T a
+        for (int i = 0; i < 3; i++)
+          for (int j = 0; j < 3; j++)
+            for (int k = 0; k < 3; k++) u[i][j] += t[i][k] * r[k][j];  // (R^T a) R
+        std::memcpy(a, u, sizeof(a));
+      }
+  }
+  double off = std::fabs(a[0][1]) + std::fabs(a[0][2]) + std::fabs(a[1][2]);
+  return std::max(a[0][0], std::max(a[1][1], a[2][2])) + off;  // Gershgorin: never below the true maximum
+}
+// false: no record (the shape is never culled)
+inline bool shape_cull_record(const RtScene* s, const RtShape& sh, float out[12]) {
+  const uint32_t kind = sh.kind_flags & RT_SHAPE_KIND_MASK;
+  if (kind != RT_CUBE && kind != RT_SPHERE) return false;
+  if (sh.xform >= s->n_xforms) return false;
+  const float* m = s->xforms[sh.xform].m;
+  double A[3][3], t[3];
+  for (int r = 0; r < 3; r++) {
+    for (int c = 0; c < 3; c++) A[r][c] = m[4 * r + c];
+    t[r] = m[4 * r + 3];
+  }
+  double det = A[0][0] * (A[1][1] * A[2][2] - A[1][2] * A[2][1]) - A[0][1] * (A[1][0] * A[2][2] - A[1][2] * A[2][0]) +
+               A[0][2] * (A[1][0] * A[2][1] - A[1][1] * A[2][0]);
+  if (!std::isfinite(det) || !(std::fabs(det) > 1e-300)) return false;
+  double B[3][3];  // A^-1: object -> outer space
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) {
+      int r1 = (c + 1) % 3, r2 = (c + 2) % 3, c1 = (r + 1) % 3, c2 = (r + 2) % 3;
+      B[r][c] = (A[r1][c1] * A[r2][c2] - A[r1][c2] * A[r2][c1]) / det;
+    }
+  double nA = 0, nB = 0, nt = 0;
+  for (int r = 0; r < 3; r++) {
+    for (int c = 0; c < 3; c++) nA += A[r][c] * A[r][c], nB += B[r][c] * B[r][c];
+    nt += t[r] * t[r];
+  }
+  nA = std::sqrt(nA), nB = std::sqrt(nB), nt = std::sqrt(nt);
+  double cp[3];  // image of the object-space origin: A^-1 (0 - t)
+  for (int r = 0; r < 3; r++) cp[r] = -(B[r][0] * t[0] + B[r][1] * t[1] + B[r][2] * t[2]);
+  const double ncp = std::sqrt(cp[0] * cp[0] + cp[1] * cp[1] + cp[2] * cp[2]);
+  double R = 0, rl = 0, k1 = 0, k0 = 0, kq = 0;
+  if (kind == RT_CUBE) {
+    rl = std::sqrt(3.0);
+    for (int k = 0; k < 8; k++) {
+      double q[3] = {k & 1 ? 1.0 : -1.0, k & 2 ? 1.0 : -1.0, k & 4 ? 1.0 : -1.0};
+      double d2 = 0;
+      for (int r = 0; r < 3; r++) {
+        double v = B[r][0] * q[0] + B[r][1] * q[1] + B[r][2] * q[2];
+        d2 += v * v;
+      }
+      R = std::max(R, std::sqrt(d2));
+    }
+    k1 = 4e-4 * nB * nB * nA;
+    k0 = 4e-4 * nB * nB * rl;
+  } else {
+    rl = 1.0;
+    double btb[3][3] = {};
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++)
+        for (int k = 0; k < 3; k++) btb[i][j] += B[k][i] * B[k][j];
+    R = std::sqrt(sym3_max_eig(btb)) * (1.0 + 1e-9);
+    kq = 1e-5 * nA * nA * nB;  // with the constant part (|o'| < 1: the error is relative to 1, not to |o'|^2) in q0
+  }
+  const double q1 = 4e-6 * nB * nA;
+  const double q0 = 4e-6 * nB * (nA * ncp + nt + rl) + 1e-6 * (ncp + R)  // last term: c itself is rounded to f32
+                    + (kind == RT_SPHERE ? 1e-5 * nB : 0.0);
+  const double v[12] = {cp[0], cp[1], cp[2], R * (1.0 + 1e-4), q1, q0, kq, k1, k0, 0, 0, 0};
+  for (double x : v)
+    if (!std::isfinite(x) || std::fabs(x) > 1e30) return false;
+  for (int i = 0; i < 3; i++) out[i] = (float)v[i];
+  for (int i = 3; i < 9; i++) out[i] = std::nextafter((float)v[i], INFINITY);
+  out[9] = out[10] = out[11] = 0.f;
+  return true;
+}
+
+
 }  // namespace rtaccel

@@ -25,6 +25,7 @@
 #define RT_BLOCK 256         // threads per block of every kernel that traces (LDS stack stride): 256 or 64
 #endif
 #define RT_AUX_NONE 0xFFFFFFFFu
+#define RT_SHAPE_CULLABLE 0x40u  // device copy of a shape: `prim` holds the index of its cull record
 #define RT_NODE_AUX 0x4u      // device copy only: this node is the root of a subtree covered by an auxiliary BVH
 #define RT_NODE_HAS_NOSHADOW 0x8u  // device copy only: a shape with shadow() == false lives in this subtree
 #ifndef RT_CONE_MIN_PAD
@@ -32,6 +33,7 @@
 #endif
 #define RT_SCENE_HAS_NOSHADOW 0x1u // Scene::props: some shape has shadow() == false
 #define RT_SCENE_SHADOW_TWO_PASS 0x4u // Scene::props: shadow-less shapes exist AND auxiliary BVHs exist: find F first, then any occluder
+#define RT_SCENE_SHAPE_CULL 0x10u   // Scene::props: some shapes have cull records (k_render_jobs<., true>)
 #define RT_SCENE_AREA_LIGHT 0x8u   // Scene::props: some area light takes more than one sample
 #define RT_SCENE_RI_ALL_ONE 0x2u   // Scene::props: every material has refractive_index == 1 (n1 = n2 = 1 always)
 
@@ -107,6 +109,7 @@ struct Scene {
   const float* texels;
   const RtLight* lights;
   const float4* aux_nodes;  // library-built auxiliary BVHs (rt_accel.h): 5 float4 per node
+  const float4* shape_cull;  // cull spheres of cubes / spheres (rt_accel.h shape_cull_record): 3 float4 per record
   const float4* aux_tris;   // their leaf triangles: 3 float4 per triangle, p1.w = offset in the group
   uint32_t n_shapes, n_nodes, n_csg_roots, n_lights, n_loose, recursion_limit;
   uint32_t flags;  // RT_RENDER_*
@@ -486,12 +489,26 @@ struct Sink {
 };
 
 // Shape::intersect (shapes.rs:204-246): inverse-transform the ray, dispatch on kind.
-template <class Sink>
+// CULL: the kernel variant for scenes that have cull records (decided per scene: the test costs registers and ~25
+// operations per shape, which only pays where a ray meets many shapes in a row)
+template <bool CULL = false, class Sink>
 __device__ __forceinline__ void shape_intersect(const Scene& sc, uint32_t si, const Ray& ray, Sink& sink) {
   const u4n RT_CONST_AS* raw = cst(reinterpret_cast<const u4n*>(sc.shapes + si));
   u4n w0 = raw[0], w1 = raw[1];
   uint32_t kf = w0.x, xform = w0.y, prim = w1.y;
   if (!sink.takes(kf)) return;
+  if (CULL && (kf & RT_SHAPE_CULLABLE) && !(sc.flags & RT_RENDER_NO_PRUNE)) {
+    // cull sphere (rt_accel.h): a line this far from the shape is one the reference's own test rejects; skips the
+    // transform and the test.  NaN => not culled.
+    const f4n RT_CONST_AS* q = cst(reinterpret_cast<const f4n*>(sc.shape_cull)) + 3u * (size_t)prim;
+    const f4n c0 = q[0], c1 = q[1], c2 = q[2];
+    const V3 oc = v3(c0.x, c0.y, c0.z) - ray.o;
+    const V3 cr = cross(oc, ray.d);
+    const float ol2 = dot(oc, oc);
+    const float dl = __builtin_amdgcn_sqrtf(dot(ray.d, ray.d)), ol = __builtin_amdgcn_sqrtf(ol2);
+    const float thr = (dl * (((c0.w + c1.x * ol) + c1.y) + c1.z * ol2) + (c1.w * ol + c2.x)) * 1.0001f;
+    if (dot(cr, cr) > thr * thr) return;
+  }
   float mn = __uint_as_float(w1.z), mx = __uint_as_float(w1.w);
   Ray local = xform ? xf_ray(sc, xform, ray) : ray;
   float ts[4];
@@ -807,7 +824,7 @@ __device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballo
 #ifndef RT_WI_INLINE
 #define RT_WI_INLINE inline
 #endif
-template <bool COUNT>
+template <bool COUNT, bool CULL>
 __device__ RT_WI_INLINE void world_intersect(const Scene& sc, const Ray& ray, Sink& sink, Counters& cn,
                                              const bool active = true) {
   // `active` false: this lane has no ray to trace but still takes part in the wave-wide votes of the walk
@@ -894,7 +911,7 @@ __device__ RT_WI_INLINE void world_intersect(const Scene& sc, const Ray& ray, Si
           for (uint32_t k = 0; k < n_shapes; k++)
             if (descend) {
               RT_UTIL(3);
-              shape_intersect(sc, first_shape + k, cur, sink);
+              shape_intersect<CULL>(sc, first_shape + k, cur, sink);
             }
         }
         RT_TACC(t_shapes, ts);
@@ -910,7 +927,7 @@ __device__ RT_WI_INLINE void world_intersect(const Scene& sc, const Ray& ray, Si
   // loose shapes (world.rs:56-59): the last n_loose entries of shapes[]
   if (COUNT && active) cn.shape_tests += sc.n_loose;
   for (uint32_t k = sc.n_shapes - sc.n_loose; k < sc.n_shapes; k++)
-    if (active && !sink.done()) shape_intersect(sc, k, ray, sink);
+    if (active && !sink.done()) shape_intersect<CULL>(sc, k, ray, sink);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1266,7 +1283,7 @@ __device__ __forceinline__ void pk_st3(const Park& pk, int k, V3 x) {
 #define RT_REFILL_MIN 64
 #endif
 enum { ST_IDLE = 100 };
-template <bool COUNT, class Source>
+template <bool COUNT, bool CULL, class Source>
 __device__ inline void integrate(const Scene& sc, const RenderParams& rp, const Source& src, uint32_t remaining0,
                                  unsigned long long* queue, Counters& cn) {
   PendingRay stack[RT_MAX_RAY_STACK];
@@ -1351,7 +1368,7 @@ __device__ inline void integrate(const Scene& sc, const RenderParams& rp, const 
       sink.init_closest();
     const uint32_t work0 = COUNT ? cn.node_visits + cn.aux_tests + cn.tri_tests + cn.shape_tests : 0u;
     RT_T0(tw);
-    world_intersect<COUNT>(sc, tray, sink, cn, active);
+    world_intersect<COUNT, CULL>(sc, tray, sink, cn, active);
     RT_TACC(t_world, tw);
     // parked values are re-read after the traversal, not carried through it in registers: the pointer is laundered
     // so that loads below cannot be forwarded from the stores above (a "memory" clobber would do the same but also

@@ -79,6 +79,9 @@ __device__ __forceinline__ void flush_counters(const Counters& cn, unsigned long
 #ifndef RT_WAVES_PER_EU
 #define RT_WAVES_PER_EU 4
 #endif
+#ifndef RT_CULL_MIN_SHAPES
+#define RT_CULL_MIN_SHAPES 6u
+#endif
 #define RT_QUEUE_SLOT 15  // d_counters slot used as the work queue of the persistent kernels
 
 __device__ __forceinline__ Ray ray_for_pixel(const RtCamera& cam, uint32_t px, uint32_t py) {  // camera.rs:45-64
@@ -156,7 +159,7 @@ struct PixelSource {
     write_colour<COUNT>(*sc, o, (size_t)ly * cam.hsize + px, col, (float)work, ws, wc);
   }
 };
-template <bool COUNT>
+template <bool COUNT, bool CULL>
 __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAVES_PER_EU, RT_WAVES_PER_EU)))
 void k_render_jobs(Scene sc, RtCamera cam, RenderParams rp, PartInfo part, PixelOut o, unsigned long long* counters) {
 #ifdef RT_PHASE_TIMERS
@@ -164,7 +167,7 @@ void k_render_jobs(Scene sc, RtCamera cam, RenderParams rp, PartInfo part, Pixel
 #endif
   PixelSource<COUNT> src{&sc, cam, part, o, (cam.hsize + 7u) / 8u, (part.rows + 7u) / 8u};
   Counters cn = {};
-  integrate<COUNT>(sc, rp, src, sc.recursion_limit, counters + RT_QUEUE_SLOT, cn);
+  integrate<COUNT, CULL>(sc, rp, src, sc.recursion_limit, counters + RT_QUEUE_SLOT, cn);
 #ifdef RT_PHASE_TIMERS
   if ((threadIdx.x & 63) == 0) atomicAdd(counters + 14, (unsigned long long)(__builtin_readcyclecounter() - t_pixel0));
 #endif
@@ -236,12 +239,12 @@ struct RaySource {
   __device__ void first_hit(uint32_t i, const Hit& ph) const { write_ray_hit(o, i, ph); }
   __device__ void finish(uint32_t i, V3 col, uint32_t, Counters&) const { write_ray_colour(o, i, col); }
 };
-template <bool COUNT>
+template <bool COUNT, bool CULL>
 __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAVES_PER_EU, RT_WAVES_PER_EU)))
 void k_color_at_jobs(Scene sc, RenderParams rp, RayOut o, uint32_t remaining, unsigned long long* counters) {
   RaySource src{o};
   Counters cn = {};
-  integrate<COUNT>(sc, rp, src, remaining, counters + RT_QUEUE_SLOT, cn);
+  integrate<COUNT, CULL>(sc, rp, src, remaining, counters + RT_QUEUE_SLOT, cn);
   flush_counters(cn, counters);
 }
 __global__ __launch_bounds__(RT_BLOCK) void k_color_at_direct(Scene sc, RenderParams rp, RayOut o, uint32_t remaining,
@@ -519,7 +522,33 @@ int rt_scene_create(RtContext* ctx, const RtScene* s, RtDeviceScene** out) {
     return rc;                                                \
   }
   UP(d.xforms, s->xforms, (size_t)s->n_xforms)
-  UP(d.shapes, s->shapes, (size_t)s->n_shapes)
+  {
+    // device copy of the shapes: bounded analytic shapes get a cull record (rt_accel.h), its index in `prim`
+    std::vector<RtShape> shapes(s->shapes, s->shapes + s->n_shapes);
+    std::vector<float> cull;
+    // worth its ~25 operations per test only where a ray meets many shapes in a row: the loose shapes of the world or
+    // the own shapes of one group, when there are at least RT_CULL_MIN_SHAPES of them
+    for (uint32_t i = 0; i < s->n_shapes; i++) {
+      float rec[12];
+      const int32_t par = shapes[i].parent;
+      const uint32_t siblings = par >= 0 ? s->nodes[par].n_shapes : s->n_loose_shapes;
+      if (siblings >= RT_CULL_MIN_SHAPES && rtaccel::shape_cull_record(s, shapes[i], rec)) {
+        shapes[i].prim = (uint32_t)(cull.size() / 12);
+        shapes[i].kind_flags |= RT_SHAPE_CULLABLE;
+        cull.insert(cull.end(), rec, rec + 12);
+      }
+    }
+    const float* dc = nullptr;
+    UP(d.shapes, shapes.data(), shapes.size())
+    UP(dc, cull.data(), cull.size())
+    d.shape_cull = reinterpret_cast<const float4*>(dc);
+    if (!cull.empty()) d.props |= RT_SCENE_SHAPE_CULL;
+    hipError_t e = hipStreamSynchronize(ctx->stream);  // the copies above read these temporaries
+    if (e != hipSuccess) {
+      rt_scene_destroy(ctx, ds);
+      return fail(ctx, RT_E_DEVICE, std::string("scene upload: ") + hipGetErrorString(e));
+    }
+  }
   UP(tg, s->tri_geom, (size_t)s->n_tris)
   UP(tn, s->tri_normals, (size_t)s->n_tris)
   {
@@ -638,8 +667,10 @@ static int launch_part(RtContext* ctx, const Scene& sc, const RtCamera* cam, con
     const uint64_t items = (uint64_t)((cam->hsize + 7u) / 8u) * ((part.rows + 7u) / 8u) * 64u;
     if (items >= 0xFFFFFFFFull) return fail(ctx, RT_E_ABI, "image too large");
     const uint32_t blocks = (uint32_t)std::min<uint64_t>((items + RT_BLOCK - 1) / RT_BLOCK, (uint64_t)ctx->n_cus * RT_BLOCKS_PER_CU);
-    hipLaunchKernelGGL(count ? k_render_jobs<true> : k_render_jobs<false>, dim3(blocks), dim3(RT_BLOCK), 0, stream, sc,
-                       *cam, rp, part, po, d_counters);
+    const bool cull = (sc.props & RT_SCENE_SHAPE_CULL) != 0;  // the scene has cull records (rt_scene_create)
+    auto kern = count ? (cull ? k_render_jobs<true, true> : k_render_jobs<true, false>)
+                      : (cull ? k_render_jobs<false, true> : k_render_jobs<false, false>);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(RT_BLOCK), 0, stream, sc, *cam, rp, part, po, d_counters);
   }
   HIP_TRY(ctx, hipGetLastError());
   return RT_OK;
@@ -799,8 +830,10 @@ int rt_color_at(RtContext* ctx, const RtDeviceScene* ds, const RtRenderOptions* 
                        remaining, ctx->d_counters);
   } else {
     const uint32_t blocks = std::min<uint32_t>((n + RT_BLOCK - 1) / RT_BLOCK, ctx->n_cus * RT_BLOCKS_PER_CU);
-    hipLaunchKernelGGL((sc.flags & RT_RENDER_COUNT_WORK) ? k_color_at_jobs<true> : k_color_at_jobs<false>, dim3(blocks),
-                       dim3(RT_BLOCK), 0, ctx->stream, sc, rp, ro, remaining, ctx->d_counters);
+    const bool cull = (sc.props & RT_SCENE_SHAPE_CULL) != 0;
+    auto kern = (sc.flags & RT_RENDER_COUNT_WORK) ? (cull ? k_color_at_jobs<true, true> : k_color_at_jobs<true, false>)
+                                                  : (cull ? k_color_at_jobs<false, true> : k_color_at_jobs<false, false>);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(RT_BLOCK), 0, ctx->stream, sc, rp, ro, remaining, ctx->d_counters);
   }
   TRY_CLEAN(hipGetLastError());
   TRY_CLEAN(hipEventRecord(ctx->ev1, ctx->stream));

@@ -199,6 +199,72 @@ def test_ragged_frames_match_oracle(size):
     assert np.array_equal(canvas.view(np.uint32), full.view(np.uint32)) and np.array_equal(idc, ids)
 
 
+def _random_solids(world, rng, n_group, n_loose):
+    """Cubes and spheres with anisotropic scales (0.02 .. 4), rotations, shears and translations: some in two groups
+    (one of them transformed), the rest loose.  Enough shapes per list for the cull records to be built."""
+    def solid(i):
+        kind = "cube" if i % 2 else "sphere"
+        ops = [("scale", *rng.uniform(0.02, 4.0, 3) ** rng.choice([1.0, 0.3])),
+               ("rotate-x", rng.uniform(-3, 3)), ("rotate-z", rng.uniform(-3, 3)),
+               ("shear", *(rng.uniform(-0.5, 0.5, 6) * (i % 3 == 0))),
+               ("translate", *rng.uniform(-6, 6, 3))]
+        mat = B.Material(color=tuple(rng.uniform(0, 1, 3)), reflective=float(i % 4 == 0) * 0.3,
+                         transparency=float(i % 5 == 0) * 0.5, refractive_index=1.0 + 0.5 * (i % 5 == 0))
+        return world.shape(kind, ops, mat, shadow=bool(i % 7))
+    g1, g2 = world.group(()), world.group([("rotate-y", 0.7), ("scale", 1.5, 0.75, 1.2), ("translate", 1, -2, 0.5)])
+    for i in range(n_group):
+        world.group_add_shape(g1 if i % 2 else g2, solid(i))
+    world.add_group(g1)
+    world.add_group(g2)
+    for i in range(n_loose):
+        world.add_shape(solid(100 + i))
+    world.add_point_light((-10, 12, -10), (1, 1, 1))
+
+
+def test_shape_cull_spheres_change_nothing():
+    """rt_accel.h shape_cull_record: rays the cull spheres reject are rays the reference's own tests reject.  Random
+    cubes and spheres (thin, sheared, rotated; grouped and loose) against random rays, including rays aimed to graze
+    the shapes, axis-parallel and non-unit directions: hit ids and t bit-identical to the oracle, which has no culling."""
+    rng = np.random.RandomState(5)
+    gw, ow = host.new_world(0), _oracle().new_world()
+    _random_solids(gw, np.random.RandomState(9), 16, 14)
+    _random_solids(ow, np.random.RandomState(9), 16, 14)
+    acc = abi.scene_arrays(gw.flatten())
+    assert len(acc["nodes"]) == 2 and acc["n_loose_shapes"] == 14
+    n = 120000
+    o = rng.uniform(-14, 14, size=(n, 3)).astype(np.float32)
+    tgt = rng.uniform(-7, 7, size=(n, 3)).astype(np.float32)
+    d = tgt - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    k = n // 10
+    d[:k] *= rng.uniform(1e-3, 1e3, size=(k, 1)).astype(np.float32)
+    d[k:2 * k, 0] = 0.0
+    d[2 * k:3 * k, 1] = 3e-5
+    d[3 * k:4 * k, 2] = 0.0
+    o[4 * k:5 * k] *= 30.0
+    d[4 * k:5 * k] = tgt[4 * k:5 * k] - o[4 * k:5 * k]
+    d[4 * k:5 * k] /= np.linalg.norm(d[4 * k:5 * k], axis=1, keepdims=True)
+    for remaining in (0, 3):
+        grgb, gt, gid, _ = gw.color_at(o, d, remaining)
+        rrgb, rt, rid, _ = ow.color_at(o, d, remaining)
+        assert np.array_equal(gid, rid), f"{(gid != rid).sum()} hit ids differ"
+        hit = rid >= 0
+        assert hit.mean() > 0.3
+        assert np.array_equal(gt[hit].view(np.uint32), rt[hit].view(np.uint32))
+        both_nan = np.isnan(grgb).any(axis=1) & np.isnan(rrgb).any(axis=1)
+        dd = np.abs(to_u8(np.nan_to_num(grgb)).astype(int) - to_u8(np.nan_to_num(rrgb)).astype(int)).max(axis=1)
+        assert ((dd <= 1) | both_nan).mean() >= LSB_FRACTION
+
+
+@pytest.mark.parametrize("name", ["cover", "checkered_cube"])
+def test_shape_culling_changes_nothing_at_4k(name):
+    """cover.yaml at 4K (BASELINE config 2; 18 loose solids => cull records): bit-identical with RT_RENDER_NO_PRUNE."""
+    raw = Raw(Scene.from_file(scene_path(name)), (3840, 2160))
+    base, ids, _ = raw.render()
+    rgb, oid, _ = raw.render(flags=abi.RT_RENDER_NO_PRUNE)
+    assert np.array_equal(rgb.view(np.uint32), base.view(np.uint32)) and np.array_equal(oid, ids)
+
+
 def test_accel_and_pruning_change_nothing_at_4k():
     """dragons at 4K (BASELINE config 5, synthetic mesh): the auxiliary BVHs and the distance pruning are
     pure culling — bit-identical image and ids with either or both switched off."""
