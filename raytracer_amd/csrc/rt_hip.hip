@@ -410,6 +410,7 @@ RenderParams make_params(const RtRenderOptions* o) {
   rp.jitter_mode = o ? o->jitter_mode : RT_JITTER_CONST;
   rp.jitter_value = o ? o->jitter_value : 0.5f;
   rp.seed = o ? o->seed : 0;
+  rp.queue_chunk = 1;
   return rp;
 }
 
@@ -648,6 +649,13 @@ void rt_accel_free(RtAccelView* v) {
 uint32_t rt_part_rows(const RtCamera* cam, const RtRenderOptions* o) { return cam ? make_part(cam, o).rows : 0; }
 
 // One kernel launch: the rows of `part` into d_out_rgb / d_aux, counters (and the work queue) in `d_counters`.
+#define RT_LIGHT_SCENE_SHAPES 16u
+#ifndef RT_LIGHT_SCENE_DRAWS
+#define RT_LIGHT_SCENE_DRAWS 2u
+#endif
+#ifndef RT_LIGHT_SCENE_CHUNK
+#define RT_LIGHT_SCENE_CHUNK 4u
+#endif
 static int launch_part(RtContext* ctx, const Scene& sc, const RtCamera* cam, const RenderParams& rp, const PartInfo& part,
                        float* d_out_rgb, const RtAux* d_aux, hipStream_t stream, unsigned long long* d_counters) {
   HIP_TRY(ctx, hipMemsetAsync(d_counters, 0, RT_N_COUNTERS * sizeof(unsigned long long), stream));
@@ -670,7 +678,14 @@ static int launch_part(RtContext* ctx, const Scene& sc, const RtCamera* cam, con
     const bool cull = (sc.props & RT_SCENE_SHAPE_CULL) != 0;  // the scene has cull records (rt_scene_create)
     auto kern = count ? (cull ? k_render_jobs<true, true> : k_render_jobs<true, false>)
                       : (cull ? k_render_jobs<false, true> : k_render_jobs<false, false>);
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(RT_BLOCK), 0, stream, sc, *cam, rp, part, po, d_counters);
+    // A scene of a few shapes has cheap tiles throughout, and its frame time is the queue's atomics: draw up to
+    // RT_LIGHT_SCENE_CHUNK tiles at a time, as long as every wave still gets RT_LIGHT_SCENE_DRAWS draws
+    // (integrate's refill).
+    RenderParams rq = rp;
+    const uint64_t waves = (uint64_t)blocks * (RT_BLOCK / 64u);
+    if (sc.n_nodes == 0 && sc.n_shapes <= RT_LIGHT_SCENE_SHAPES)
+      rq.queue_chunk = (uint32_t)std::clamp<uint64_t>(items / 64u / (waves * RT_LIGHT_SCENE_DRAWS), 1u, RT_LIGHT_SCENE_CHUNK);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(RT_BLOCK), 0, stream, sc, *cam, rq, part, po, d_counters);
   }
   HIP_TRY(ctx, hipGetLastError());
   return RT_OK;

@@ -199,6 +199,26 @@ def test_ragged_frames_match_oracle(size):
     assert np.array_equal(canvas.view(np.uint32), full.view(np.uint32)) and np.array_equal(idc, ids)
 
 
+@pytest.mark.parametrize("name,size", [("csg", (1925, 1083)), ("checkered_sphere", (3837, 2161)), ("basic_scene", (2563, 1437))])
+def test_chunked_queue_draws_change_nothing(name, size):
+    """Scenes of a few shapes draw several tiles from the work queue per atomic once a frame is large (launch_part's
+    queue_chunk: 3 tiles at 1925x1083, 4 at 4K).  The same ragged frame rendered as 16 interleaved parts, each too
+    small for chunking, is the same bytes, and every pixel is traced exactly once."""
+    from raytracer_amd import tiles
+    raw = Raw(Scene.from_file(scene_path(name)), size)
+    full, ids, st = raw.render()
+    assert st.overflow == 0 and st.primary == size[0] * size[1]
+    canvas, idc = np.full_like(full, np.nan), np.full_like(ids, -9)
+    primary = 0
+    for p in range(16):
+        rgb, oid, s = raw.render(tile_h=8, n_parts=16, part=p)
+        rows = tiles.part_rows(size[1], 8, 16, p)
+        canvas[rows], idc[rows] = rgb, oid
+        primary += s.primary
+    assert primary == st.primary
+    assert np.array_equal(canvas.view(np.uint32), full.view(np.uint32)) and np.array_equal(idc, ids)
+
+
 def _random_solids(world, rng, n_group, n_loose):
     """Cubes and spheres with anisotropic scales (0.02 .. 4), rotations, shears and translations: some in two groups
     (one of them transformed), the rest loose.  Enough shapes per list for the cull records to be built."""
