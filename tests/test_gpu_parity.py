@@ -63,6 +63,38 @@ def test_scene_matches_reference_render(name, obj_files):
     assert float((d <= 1).mean()) >= LSB_FRACTION, f"{name}: {(d > 1).sum()} pixels off by more than 1 LSB"
 
 
+def _write_ppm(path, rng, w, h, binary):
+    """A seeded stand-in for the textures the reference does not ship (README.md:120-138): smooth gradients plus noise,
+    so that a texel picked one off shows up as a colour error."""
+    y, x = np.mgrid[0:h, 0:w]
+    img = np.stack([(x * 255) // max(w - 1, 1), (y * 255) // max(h - 1, 1), (x + y) % 256], axis=2)
+    img = ((img + rng.randint(0, 64, size=img.shape)) % 256).astype(np.uint8)
+    with open(path, "wb") as f:
+        if binary:
+            f.write(b"P6\n%d %d\n255\n" % (w, h) + img.tobytes())
+        else:
+            f.write(b"P3\n%d %d\n255\n" % (w, h) + b"\n".join(b" ".join(b"%d" % v for v in row.ravel()) for row in img) + b"\n")
+
+
+@pytest.mark.parametrize("name,files,tex", [
+    ("earth", ["earthmap1k.ppm"], (96, 48)),
+    ("skybox", ["negx.ppm", "posx.ppm", "negy.ppm", "posy.ppm", "negz.ppm", "posz.ppm"], (40, 40))])
+def test_image_textures_match_oracle(name, files, tex, tmp_path):
+    """earth.yaml / skybox.yaml (UvImage through the spherical and the cube map, uv_pattern.rs:117-132) with seeded
+    synthetic PPMs in place of the downloads the reference names: the texel tables in HBM give the oracle's colours."""
+    rng = np.random.RandomState(3)
+    paths = []
+    for k, f in enumerate(files):
+        paths.append(str(tmp_path / f))
+        _write_ppm(paths[-1], rng, tex[0], tex[1], binary=k % 2 == 0)
+    scene = Scene.from_file(scene_path(name), ppm_files=paths)
+    cam = scene.camera(480, 270)
+    g = scene.build(host.new_world(0)).render(cam, aux=True)
+    r = scene.build(_oracle().new_world()).render(cam, aux=True)
+    check(g, r, name)
+    assert len(np.unique(to_u8(g.rgb).reshape(-1, 3), axis=0)) > 500  # the texture is what is seen
+
+
 @pytest.mark.parametrize("mode,seed", [(B.JITTER_CONST, 0), (B.JITTER_COUNTER, 1), (B.JITTER_COUNTER, 12345)])
 def test_soft_shadows_area_light(mode, seed):
     scene = Scene.from_file(scene_path("soft_shadows"))
