@@ -40,7 +40,7 @@ def check(g, r, name):
 
 SCENES = [("basic_scene", None), ("cover", (640, 640)), ("csg", None), ("checkered_cube", None),
           ("checkered_sphere", None), ("checkered_plane", None), ("checkered_cylinder", None), ("space_ship", (640, 360)),
-          ("space_teapot", (640, 360))]
+          ("space_teapot", (640, 360)), ("teapot_low", (480, 270))]
 
 
 @pytest.mark.parametrize("name,size", SCENES)
