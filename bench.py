@@ -3,7 +3,8 @@
 
 A "step" is one full frame of the workload: every rank renders its interleaved scanline tiles
 with the HIP kernels (scene already resident in HBM), then (N > 1) the canvases are all-gathered
-over RCCL and de-interleaved.  value = rays of the whole frame / mean step time, in Mrays/s, where a
+over RCCL and de-interleaved; frames are double-buffered, so the all-gather of one frame runs beside the
+render of the next (every frame is assembled on every rank before the clock stops).  value = rays of the whole frame / mean step time, in Mrays/s, where a
 ray is one World::intersect-equivalent query (primary + shadow + reflect + refract).
 
 Default workload: samples/scenes/dragons.yaml at 3840x2160 (BASELINE.json: "frame time 4K dragons")
@@ -59,8 +60,14 @@ def main():
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--tile-h", type=int, default=8)  # a multiple of 8 keeps every 8x8 wave tile inside one stripe
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-gather", action="store_true")  # rehearse the N > 1 exchange step on one GPU (RCCL, world 1)
     ap.add_argument("--cpu-sample-pixels", type=int, default=900000)  # ~15 s of oracle work on 16 threads
     args = ap.parse_args()
+
+    # stdout carries the one JSON line and nothing else: libraries that print there (RCCL's version banner) go to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -71,8 +78,15 @@ def main():
         raise SystemExit("bench.py needs a GPU: there is no CPU render path in the product")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+    # one stream of our own for the render launches, torch's copies and RCCL's ordering: torch's default stream is
+    # the null stream, whose handle 0 rt_render_device reads as "the context's stream" (include/rt_abi.h)
+    torch.cuda.set_stream(torch.cuda.Stream(dev))
+    gather = world > 1 or args.force_gather
+    if gather:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     scene, mesh_label = load_workload(args.workload)
     cam = scene.camera(args.width, args.height)
@@ -86,9 +100,10 @@ def main():
     opts = abi.RtRenderOptions(abi.RT_JITTER_COUNTER, 0.5, 1, args.tile_h, world, rank, 0)
     rows = int(lib.rt_part_rows(C.byref(rcam), C.byref(opts)))
     max_rows = tiles.max_part_rows(cam.vsize, args.tile_h, world)
-    local = torch.zeros((max_rows, cam.hsize, 3), dtype=torch.float32, device=dev)
-    gathered = torch.empty((world, max_rows, cam.hsize, 3), dtype=torch.float32, device=dev) if world > 1 else None
-    perm = torch.from_numpy(tiles.row_permutation(cam.vsize, args.tile_h, world)).to(dev) if world > 1 else None
+    # N > 1: frames are double-buffered, the all-gather of one frame (RCCL's stream) runs beside the next render
+    pipe = tiles.CanvasPipeline(cam.vsize, cam.hsize, args.tile_h, dev) if gather else None
+    local = pipe.local[0] if gather else torch.zeros((max_rows, cam.hsize, 3), dtype=torch.float32, device=dev)
+    assert local.shape[0] == max_rows
     stream = torch.cuda.current_stream(dev)
 
     def check(rc, what):
@@ -96,15 +111,16 @@ def main():
             raise RuntimeError(f"{what} failed ({rc}): {lib.rt_last_error(ctx).decode()}")
 
     def step():
-        check(lib.rt_render_device(ctx, dscene, C.byref(rcam), C.byref(opts), local.data_ptr(), None,
+        mine = pipe.next_local() if gather else local
+        check(lib.rt_render_device(ctx, dscene, C.byref(rcam), C.byref(opts), mine.data_ptr(), None,
                                    C.c_void_p(stream.cuda_stream), None), "rt_render_device")
-        if world > 1:
-            return tiles.gather_canvas(local, cam.vsize, args.tile_h, perm=perm, gathered=gathered)
-        return local
+        return pipe.submit() if gather else mine  # the canvas of the frame before (None for the first) when gathering
 
-    def sync():
+    def sync():  # every frame submitted so far is assembled on every rank when this returns
+        if gather:
+            pipe.finish()
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if gather:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
@@ -120,11 +136,16 @@ def main():
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        canvas = step()
+        step()
     sync()
     elapsed = time.perf_counter() - t0
+    if gather:  # outside the timed region: this rank's rows of the last assembled canvas are the rows it rendered
+        last = (pipe.frame - 1) % 2
+        mine_rows = torch.from_numpy(tiles.part_rows(cam.vsize, args.tile_h, world, rank)).to(dev)
+        if not torch.equal(pipe.canvas[last].index_select(0, mine_rows), pipe.local[last][: len(mine_rows)]):
+            raise RuntimeError("gathered canvas does not hold this rank's rows")
     tot = torch.tensor([elapsed, float(my_rays)], dtype=torch.float64, device=dev)
-    if world > 1:
+    if gather:
         tmax = tot.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
@@ -199,8 +220,9 @@ def main():
                        "frame_ms": round(ms_per_step, 3), "scene_setup_s": round(setup_s, 1)},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if gather:
         dist.destroy_process_group()
 
 

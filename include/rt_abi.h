@@ -270,7 +270,9 @@ int rt_render(RtContext*, const RtDeviceScene*, const RtCamera*, const RtRenderO
               RtAux* aux /* host pointers, may be NULL */, RtStats* stats /* may be NULL */);
 
 /* Same, but out_rgb / aux are DEVICE pointers on the context's GPU and nothing is copied back;
- * `stream` is a hipStream_t (NULL = the context's own stream). The call is asynchronous unless
+ * `stream` is a hipStream_t (NULL = the context's own stream, NOT the legacy null stream: a caller whose
+ * other work is on the null stream, e.g. torch's default stream, must create a stream, pass it here and
+ * run that other work on it, or synchronise). The call is asynchronous unless
  * stats != NULL (then it synchronises the stream to read the counters and event times). */
 int rt_render_device(RtContext*, const RtDeviceScene*, const RtCamera*, const RtRenderOptions*, float* d_out_rgb,
                      RtAux* d_aux, void* stream, RtStats* stats);

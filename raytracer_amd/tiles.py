@@ -45,3 +45,44 @@ def gather_canvas(local: torch.Tensor, vsize: int, tile_h: int, group=None, perm
     if perm is None:
         perm = torch.from_numpy(row_permutation(vsize, tile_h, n)).to(local.device)
     return flat.index_select(0, perm)
+
+
+class CanvasPipeline:
+    """Frames in flight: the all-gather of frame k runs beside the render of frame k+1.
+
+    Two sets of buffers (this rank's rows, the gathered blocks, the assembled canvas), no allocation per frame.
+    Per frame: render into ``next_local()``, then ``submit()``, which starts that frame's all-gather without
+    waiting for it and returns the assembled canvas of the frame before (None for the first); ``finish()`` returns
+    the last one.  A returned canvas stays valid until the second ``submit()`` after it.  On GPUs the collective
+    runs on RCCL's own stream; the waits are stream-side, so the host runs ahead."""
+
+    def __init__(self, vsize: int, hsize: int, tile_h: int, device, group=None, dtype=torch.float32):
+        self.group = group
+        n = dist.get_world_size(group)
+        m = max_part_rows(vsize, tile_h, n)
+        self.local = [torch.zeros((m, hsize, 3), dtype=dtype, device=device) for _ in range(2)]
+        self.gathered = [torch.empty((n * m, hsize, 3), dtype=dtype, device=device) for _ in range(2)]
+        self.canvas = [torch.empty((vsize, hsize, 3), dtype=dtype, device=device) for _ in range(2)]
+        self.perm = torch.from_numpy(row_permutation(vsize, tile_h, n)).to(device)
+        self.pending = None
+        self.frame = 0
+
+    def next_local(self) -> torch.Tensor:
+        return self.local[self.frame % 2]
+
+    def submit(self):
+        slot = self.frame % 2
+        work = dist.all_gather_into_tensor(self.gathered[slot], self.local[slot], group=self.group, async_op=True)
+        done = self.finish()
+        self.pending = (work, slot)
+        self.frame += 1
+        return done
+
+    def finish(self):
+        if self.pending is None:
+            return None
+        work, slot = self.pending
+        self.pending = None
+        work.wait()
+        torch.index_select(self.gathered[slot], 0, self.perm, out=self.canvas[slot])
+        return self.canvas[slot]

@@ -176,6 +176,7 @@ class Raw:
         oid = torch.full((max(rows, 1), self.cam.hsize), -7, dtype=torch.int32, device=self.dev)
         aux = abi.RtAux(None, oid.data_ptr(), None)
         st = abi.RtStats()
+        torch.cuda.synchronize()  # torch filled the buffers on the null stream; the render runs on the context's stream
         rc = self.lib.rt_render_device(self.ctx, self.ds, C.byref(self.rcam), C.byref(opts), out.data_ptr(), C.byref(aux),
                                        None, C.byref(st) if want_stats else None)
         assert rc == abi.RT_OK, self.lib.rt_last_error(self.ctx).decode()
@@ -369,3 +370,14 @@ def test_world_without_lights_is_black():
     w.add_shape(w.shape("sphere", (), B.Material(reflective=0.5)))
     rgb, t, ids, _ = w.color_at([(0, 0, -5)], [(0, 0, 1)], 4)
     assert np.array_equal(rgb[0], [0, 0, 0]) and ids[0] == 0 and t[0] == 4.0
+
+
+def test_gather_pipeline_over_rccl(root):
+    """bench.py's N > 1 exchange step on one GPU: tiles.CanvasPipeline over RCCL (world size 1, in a process of its
+    own), renders launched on torch's stream.  Every assembled canvas is the frame rendered synchronously."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "gpu_gather_rehearsal.py"), "5"], capture_output=True,
+                       text=True, timeout=240)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("frame ")]
+    assert r.returncode == 0 and len(lines) == 5 and all("mismatching pixels 0," in ln for ln in lines), r.stdout + r.stderr[-2000:]

@@ -63,3 +63,41 @@ def test_gather_canvas_gloo(tmp_path, world, tile_h, size):
     port = 29600 + (os.getpid() % 300) + world
     mp.spawn(_worker, args=(world, port, fp, tile_h, op), nprocs=world, join=True)
     assert np.load(op)[0] == 1
+
+
+def _pipeline_worker(rank, world, port, full_path, tile_h, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        full = torch.from_numpy(np.load(full_path))
+        vsize, hsize = full.shape[:2]
+        mine = torch.from_numpy(tiles.part_rows(vsize, tile_h, world, rank))
+        pipe = tiles.CanvasPipeline(vsize, hsize, tile_h, torch.device("cpu"))
+        ok, done = True, []
+        for k in range(5):  # frame k = the render scaled by k + 1: every frame must come back as itself, in order
+            local = pipe.next_local()
+            local.zero_()
+            local[: len(mine)] = full[mine] * float(k + 1)
+            out = pipe.submit()
+            if out is not None:
+                done.append(out.clone())
+        done.append(pipe.finish().clone())
+        ok = len(done) == 5 and all(torch.equal(c, full * float(k + 1)) for k, c in enumerate(done)) and pipe.finish() is None
+        flag = torch.tensor([1 if ok else 0])
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if rank == 0:
+            np.save(out_path, np.array([int(flag.item())]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,tile_h,size", [(2, 8, (48, 37)), (3, 2, (40, 25))])
+def test_canvas_pipeline_gloo(tmp_path, world, tile_h, size):
+    """bench.py's N > 1 path: double-buffered frames, the gather of one frame overlapping the next render."""
+    rng = np.random.RandomState(5)
+    full = rng.uniform(0, 1, size=(size[1], size[0], 3)).astype(np.float32)
+    fp, op = str(tmp_path / "full.npy"), str(tmp_path / "ok.npy")
+    np.save(fp, full)
+    port = 29950 + (os.getpid() % 300) + world
+    mp.spawn(_pipeline_worker, args=(world, port, fp, tile_h, op), nprocs=world, join=True)
+    assert np.load(op)[0] == 1
