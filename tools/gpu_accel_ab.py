@@ -35,6 +35,7 @@ def render(flags):
     ht = torch.zeros((H, W), dtype=torch.float32, device=dev)
     aux = abi.RtAux(None, oid.data_ptr(), ht.data_ptr())
     st = abi.RtStats()
+    torch.cuda.synchronize()  # torch's fills ran on the null stream, the render uses the context's stream
     rc = lib.rt_render_device(ctx, ds, C.byref(rcam), C.byref(opts), out.data_ptr(), C.byref(aux), None, C.byref(st))
     if rc != 0:
         raise RuntimeError(f"rc={rc} {lib.rt_last_error(ctx).decode()}")

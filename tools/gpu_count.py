@@ -26,6 +26,7 @@ for spec in sys.argv[1:]:
         opts = abi.RtRenderOptions(abi.RT_JITTER_COUNTER, 0.5, 1, 1, 1, 0, flags)
         st = abi.RtStats()
         for _ in range(2):
+            torch.cuda.synchronize()  # torch's fills ran on the null stream, the render uses the context's stream
             rc = lib.rt_render_device(ctx, ds, C.byref(rcam), C.byref(opts), out.data_ptr(), None, None, C.byref(st))
             assert rc in (0, -5), lib.rt_last_error(ctx).decode()
         print(spec, "flags", flags, {f: getattr(st, f) for f, _ in st._fields_}, flush=True)

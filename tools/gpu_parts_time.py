@@ -12,6 +12,7 @@ def run(W, H, n, part, tile_h=2):
     opts = abi.RtRenderOptions(abi.RT_JITTER_COUNTER, 0.5, 1, tile_h, n, part, 0)
     st = abi.RtStats(); ms = []
     for _ in range(4):
+        torch.cuda.synchronize()  # torch's fills ran on the null stream, the render uses the context's stream
         assert lib.rt_render_device(ctx, ds, C.byref(rcam), C.byref(opts), out.data_ptr(), None, None, C.byref(st)) == 0
         ms.append(st.kernel_ms)
     return min(ms), st.primary + st.shadow + st.reflect + st.refract

@@ -20,6 +20,7 @@ for name in names:
         opts = abi.RtRenderOptions(abi.RT_JITTER_COUNTER, 0.5, 1, 1, 1, 0, flags)
         st = abi.RtStats(); ms = []
         for _ in range(4):
+            torch.cuda.synchronize()  # torch's fills ran on the null stream, the render uses the context's stream
             assert lib.rt_render_device(ctx, ds, C.byref(rcam), C.byref(opts), out.data_ptr(), C.byref(aux), None, C.byref(st)) == 0
             ms.append(st.kernel_ms)
         res[flags] = (out.cpu().numpy(), oid.cpu().numpy(), ht.cpu().numpy(), min(ms))

@@ -28,6 +28,7 @@ for spec in specs:
     opts = abi.RtRenderOptions(abi.RT_JITTER_COUNTER, 0.5, 1, 1, 1, 0, 0)
     ms, st = [], abi.RtStats()
     for _ in range(6):
+        torch.cuda.synchronize()  # torch's fills ran on the null stream, the render uses the context's stream
         rc = lib.rt_render_device(ctx, ds, C.byref(rcam), C.byref(opts), out.data_ptr(), None, None, C.byref(st))
         assert rc in (0, -5), lib.rt_last_error(ctx).decode()  # -5: list overflow (experiments with small caps)
         ms.append(st.kernel_ms)

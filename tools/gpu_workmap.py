@@ -13,6 +13,7 @@ wm = torch.zeros((H, W), dtype=torch.float32, device=dev)
 aux = abi.RtAux(None, None, wm.data_ptr())
 opts = abi.RtRenderOptions(abi.RT_JITTER_COUNTER, 0.5, 1, 1, 1, 0, abi.RT_RENDER_COUNT_WORK | abi.RT_RENDER_WORK_MAP)
 st = abi.RtStats()
+torch.cuda.synchronize()  # torch's fills ran on the null stream, the render uses the context's stream
 assert lib.rt_render_device(ctx, ds, C.byref(rcam), C.byref(opts), out.data_ptr(), C.byref(aux), None, C.byref(st)) == 0
 w = wm.cpu().numpy()
 for bit, nm in ((0x10, "shadow"), (0x20, "collect")):
