@@ -444,6 +444,16 @@ struct RtbWorld {
     }
     return b;
   }
+  // What a shape really covers in its parent's space, for the flags that let the device cull by distance. The
+  // reference's box is not that for a cone: a ray parallel to the cone's side (|a| < EPSILON) gets t = -c / 2b
+  // without the min < y < max test (cone.rs:131-141), a hit anywhere on the infinite cone; and check_cap accepts
+  // x^2 + z^2 <= |y| (cone.rs:90-94), caps of radius sqrt|y|, wider than the box where |y| < 1. A cone is unbounded.
+  Box true_psb(const HShape& s) const {
+    if (s.kind != RTB_CONE) return s.psb;
+    Box b;
+    b.lo = P3{-kInf, -kInf, -kInf}, b.hi = P3{kInf, kInf, kInf};
+    return b;
+  }
   uint32_t clone_shape(uint32_t id) {
     shapes.push_back(shapes[id]);
     return (uint32_t)shapes.size() - 1;
@@ -764,7 +774,7 @@ struct Flattener {
       const HShape& hs = w.shapes[s];
       if (!(hs.kind >= RTB_TRIANGLE && hs.identity)) all_tris = false;
       emit_shape(s, (int)idx);
-      box_merge(tb, hs.psb);
+      box_merge(tb, w.true_psb(hs));
       box_merge(bb, hs.psb);
     }
     uint32_t n_shapes = (uint32_t)gr.shapes.size();

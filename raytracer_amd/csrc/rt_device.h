@@ -488,6 +488,14 @@ struct Sink {
   __device__ __forceinline__ bool done() const { return mode == SINK_ANY_SHADOW && found(); }
 };
 
+// The shape reported for a hit on `s`: the last of its value-identical duplicates (rt_scene_create; triangles only,
+// the index sits in the record's unused min slot).  Shading does not care which of them it is.
+__device__ __forceinline__ int reported_shape(const Scene& sc, int s) {
+  if (s < 0) return s;
+  const u4n w0 = cst(reinterpret_cast<const u4n*>(sc.shapes + s))[0], w1 = cst(reinterpret_cast<const u4n*>(sc.shapes + s))[1];
+  return (w0.x & RT_SHAPE_KIND_MASK) >= RT_TRIANGLE ? (int)w1.z : s;
+}
+
 // Shape::intersect (shapes.rs:204-246): inverse-transform the ray, dispatch on kind.
 // CULL: the kernel variant for scenes that have cull records (decided per scene: the test costs registers and ~25
 // operations per shape, which only pays where a ray meets many shapes in a row)
@@ -1403,7 +1411,9 @@ __device__ inline void integrate(const Scene& sc, const RenderParams& rp, const 
     } else if (job == JOB_SHADE) {
       Hit hit = Hit{sink.t, sink.u(), sink.v(), sink.shape};
       if (first) {
-        src.first_hit(item, hit);  // outputs of the primary hit go out now instead of riding along in registers
+        Hit out = hit;
+        out.shape = reported_shape(sc, hit.shape);
+        src.first_hit(item, out);  // outputs of the primary hit go out now instead of riding along in registers
         first = false;
       }
       hit_t = hit.t;

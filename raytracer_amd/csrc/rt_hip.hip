@@ -198,6 +198,7 @@ void k_render_direct(Scene sc, RtCamera cam, RenderParams rp, PartInfo part, Pix
     cn.primary = 1;
     Hit ph;
     V3 col = color_at_direct<COUNT>(sc, rp, ray_for_pixel(cam, px, py), sc.recursion_limit, py * cam.hsize + px, cn, &ph);
+    ph.shape = reported_shape(sc, ph.shape);
     write_hit(o, (size_t)ly * cam.hsize + px, ph);
     write_colour<COUNT>(sc, o, (size_t)ly * cam.hsize + px, col,
                         (float)(cn.node_visits + cn.aux_tests + cn.tri_tests + cn.shape_tests), (float)cn.work_shadow,
@@ -262,6 +263,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_color_at_direct(Scene sc, RenderPa
     Hit ph;
     V3 col = color_at_direct<false>(sc, rp, r, remaining, i, cn, &ph);
     write_ray_colour(o, i, col);
+    ph.shape = reported_shape(sc, ph.shape);
     write_ray_hit(o, i, ph);
   }
   flush_counters(cn, counters);
@@ -541,6 +543,28 @@ int rt_scene_create(RtContext* ctx, const RtScene* s, RtDeviceScene** out) {
         shapes[i].prim = (uint32_t)(cull.size() / 12);
         shapes[i].kind_flags |= RT_SHAPE_CULLABLE;
         cull.insert(cull.end(), rec, rec + 12);
+      }
+    }
+    // Which of several value-identical triangles is reported as hit (rt_device.h reported_shape). A mesh that lists
+    // a triangle twice gives two entries equal in (t, Shape, u, v), and of such neighbours the reference's
+    // Intersections keeps the LATER one (BTreeMap bulk build), whereas ties between different shapes
+    // go to the earlier. Duplicates are the same class under the same transformed ancestor; the device copy of a
+    // triangle holds the last of them in the unused `mn` slot.
+    {
+      std::vector<std::pair<uint64_t, uint32_t>> keyed;
+      for (uint32_t i = 0; i < s->n_shapes; i++)
+        if ((shapes[i].kind_flags & RT_SHAPE_KIND_MASK) >= RT_TRIANGLE) {
+          const int32_t par = shapes[i].parent;
+          const int64_t anchor = par >= 0 ? (int64_t)s->nodes[par].next_xf + 1 : 0;
+          keyed.emplace_back(((uint64_t)shapes[i].vclass << 32) | (uint64_t)anchor, i);
+          memcpy(&shapes[i].mn, &i, sizeof(uint32_t));
+        }
+      std::sort(keyed.begin(), keyed.end());
+      for (size_t a = 0; a < keyed.size();) {
+        size_t b = a + 1;
+        while (b < keyed.size() && keyed[b].first == keyed[a].first) b++;
+        for (size_t k = a; k + 1 < b; k++) memcpy(&shapes[keyed[k].second].mn, &keyed[b - 1].second, sizeof(uint32_t));
+        a = b;
       }
     }
     const float* dc = nullptr;
