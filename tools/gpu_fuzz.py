@@ -15,9 +15,26 @@ from raytracer_amd.canvas import to_u8  # noqa: E402
 from test_gpu_parity import _random_solids  # noqa: E402
 from conftest import small_dragons  # noqa: E402
 
-def mixed_world(w, rng):
-    """Every primitive kind, patterns, nested transformed groups, a divided triangle mesh, CSG trees, two lights."""
+def mixed_world(w, rng, rich=False):
+    """Every primitive kind, patterns, nested transformed groups, a divided triangle mesh, CSG trees, two lights.
+    rich: also texture maps (checker, align-check, image) through the three uv mappings, cube maps, xyz-rgb, and an
+    area light in place of one point light."""
     from raytracer_amd import builder as B
+
+    def uv(j):
+        if j % 3 == 0:
+            return w.uv_checker(float(rng.randint(2, 12)), float(rng.randint(2, 12)), tuple(rng.uniform(0, 1, 3)), tuple(rng.uniform(0, 1, 3)))
+        if j % 3 == 1:
+            return w.uv_align_check(*[tuple(rng.uniform(0, 1, 3)) for _ in range(5)])
+        return w.uv_image(rng.uniform(0, 1, size=(int(rng.randint(2, 40)), int(rng.randint(2, 40)), 3)).astype(np.float32))
+
+    def rich_pattern(i):
+        ops = [("scale", *rng.uniform(0.3, 1.5, 3)), ("rotate-y", rng.uniform(-2, 2))]
+        if i % 3 == 0:
+            return w.pattern(B.PAT_TEXTURE_MAP, None, ops, [B.UVMAP_SPHERICAL, B.UVMAP_PLANAR, B.UVMAP_CYLINDRICAL][i // 3 % 3], [uv(i // 9)])
+        if i % 3 == 1:
+            return w.pattern(B.PAT_CUBE_MAP, None, ops, 0, [uv(i + j) for j in range(6)])
+        return w.pattern(B.PAT_XYZ_RGB, None, ops)
 
     def xf():
         return [("scale", *rng.uniform(0.3, 2.5, 3)), ("rotate-x", rng.uniform(-3, 3)), ("rotate-y", rng.uniform(-3, 3)),
@@ -25,7 +42,9 @@ def mixed_world(w, rng):
 
     def mat(i):
         pat = -1
-        if i % 3 == 0:
+        if rich and i % 2 == 1:
+            pat = rich_pattern(i // 2)
+        elif i % 3 == 0:
             kind = [B.PAT_STRIPED, B.PAT_GRADIENT, B.PAT_RING, B.PAT_CHECKER][i // 3 % 4]
             pat = w.pattern(kind, [tuple(rng.uniform(0, 1, 3)), tuple(rng.uniform(0, 1, 3))],
                             [("scale", *rng.uniform(0.2, 1.5, 3)), ("rotate-z", rng.uniform(-2, 2))])
@@ -65,7 +84,10 @@ def mixed_world(w, rng):
     c2 = w.csg(int(rng.choice(ops)), B.CHILD_CSG, c1, B.CHILD_SHAPE, solid(42))
     w.add_csg(c2)
     w.add_point_light((-10, 12, -10), (0.7, 0.7, 0.7))
-    w.add_point_light((8, 9, -4), (0.4, 0.3, 0.3))
+    if rich and rng.randint(2):
+        w.add_area_light((8, 9, -4), (2, 0, 0), 2, (0, 0, 2), 3, (0.4, 0.3, 0.3))
+    else:
+        w.add_point_light((8, 9, -4), (0.4, 0.3, 0.3))
 
 
 def run_seed(seed, n=40000, log=print):
@@ -79,9 +101,10 @@ def run_seed(seed, n=40000, log=print):
         span, what = 12.0, "small dragons"
     elif seed % 4 == 1:
         gw, ow = host.new_world(0), oracle.new_world()
-        mixed_world(gw, np.random.RandomState(seed))
-        mixed_world(ow, np.random.RandomState(seed))
-        span, what = 12.0, "mixed"
+        rich = seed >= 1000
+        mixed_world(gw, np.random.RandomState(seed), rich)
+        mixed_world(ow, np.random.RandomState(seed), rich)
+        span, what = 12.0, "mixed rich" if rich else "mixed"
     else:
         gw, ow = host.new_world(0), oracle.new_world()
         _random_solids(gw, np.random.RandomState(seed), ng, nl)
