@@ -386,6 +386,17 @@ def test_fuzz_regressions(seed, root):
     assert len(lines) == 2 and not any("skipped" in ln for ln in lines), "\n".join(lines)
 
 
+@pytest.mark.parametrize("seed", [0, 1, 4, 7])
+def test_fuzz_frames(seed, root):
+    """Whole frames of tools/gpu_fuzz.py's random worlds (every primitive and pattern kind, texture and cube maps,
+    groups, a divided triangle soup, CSG; group-less with an area light for odd seeds), random cameras, odd sizes."""
+    import sys
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import gpu_fuzz
+    lines = []
+    assert gpu_fuzz.run_frame(seed, log=lines.append) == 0 and ": ok" in lines[-1], "\n".join(lines)
+
+
 def test_gather_pipeline_over_rccl(root):
     """bench.py's N > 1 exchange step on one GPU: tiles.CanvasPipeline over RCCL (world size 1, in a process of its
     own), renders launched on torch's stream.  Every assembled canvas is the frame rendered synchronously."""
