@@ -99,12 +99,45 @@ def mixed_world(w, rng, rich=False, loose=False):
         w.add_point_light((8, 9, -4), (0.4, 0.3, 0.3))
 
 
+def instanced_world(w, rng):
+    """The same opaque triangle mesh (a bumpy height field plus loose soup triangles, some listed twice) parsed into two
+    or three differently transformed, divided groups, as scene.rs does for every `obj:` instance: the auxiliary trees
+    are shared between them (rt_accel.h).  A floor, a reflective sphere, one light."""
+    from raytracer_amd import builder as B
+    n = int(rng.randint(8, 48))
+    gx, gz = np.meshgrid(np.linspace(-2, 2, n), np.linspace(-2, 2, n))
+    pos = np.stack([gx, 0.4 * np.sin(3 * gx) * np.cos(2 * gz) + rng.uniform(-0.05, 0.05, gx.shape), gz], axis=-1).reshape(-1, 3)
+    idx = np.arange(n * n).reshape(n, n)
+    a, b, c, d = idx[:-1, :-1].ravel(), idx[1:, :-1].ravel(), idx[:-1, 1:].ravel(), idx[1:, 1:].ravel()
+    tris = np.concatenate([np.stack([a, b, c], 1), np.stack([b, d, c], 1)])
+    soup = np.stack([rng.choice(n * n, 3, replace=False) for _ in range(int(rng.randint(1, 60)))]).reshape(-1, 3)
+    tris = np.concatenate([tris, soup, tris[rng.choice(len(tris), 5)]]).astype(np.int32)
+    smooth = bool(rng.randint(2))
+    nrm = np.stack([-1.2 * np.cos(3 * gx) * np.cos(2 * gz), np.ones_like(gx), 0.8 * np.sin(3 * gx) * np.sin(2 * gz)], -1).reshape(-1, 3)
+    threshold = int(rng.choice([1, 8, 50]))
+    for k in range(int(rng.randint(2, 4))):
+        g = w.group([("scale", *rng.uniform(0.5, 2.0, 3)), ("rotate-y", rng.uniform(-3, 3)), ("rotate-x", rng.uniform(-0.5, 0.5)),
+                     ("translate", *rng.uniform(-4, 4, 3))])
+        mat = B.Material(color=tuple(rng.uniform(0, 1, 3)), reflective=0.3 * (k == 1))
+        w.group_add_mesh(g, mat, pos.astype(np.float32), nrm.astype(np.float32) if smooth else None, tris, tris if smooth else None)
+        w.group_divide(g, threshold)
+        w.add_group(g)
+    w.add_shape(w.shape("plane", [("translate", 0, -3, 0)], B.Material(color=(0.8, 0.8, 0.8), reflective=0.2)))
+    w.add_shape(w.shape("sphere", [("translate", 0, 3, 0)], B.Material(color=(0.2, 0.2, 0.3), reflective=0.6)))
+    w.add_point_light((-6, 10, -8), (1, 1, 1))
+
+
 def run_seed(seed, n=40000, log=print):
     """One world and one batch of rays; returns the number of failed checks."""
     bad = 0
     rng = np.random.RandomState(1000 + seed)
     ng, nl = int(rng.randint(4, 28)), int(rng.randint(0, 24))
-    if seed % 4 == 3 and seed < 2000:
+    if seed >= 3000:
+        gw, ow = host.new_world(0), oracle.new_world()
+        instanced_world(gw, np.random.RandomState(seed))
+        instanced_world(ow, np.random.RandomState(seed))
+        span, what = 9.0, "instanced"
+    elif seed % 4 == 3 and seed < 2000:
         scene = small_dragons(int(rng.randint(8, 40)), int(rng.randint(6, 30)))
         gw, ow = scene.build(host.new_world(0)), scene.build(oracle.new_world())
         span, what = 12.0, "small dragons"
