@@ -216,7 +216,52 @@ def run_frame(seed, log=print):
     return 0
 
 
+class _FuzzScene:
+    """What tests/test_gpu_parity.py Raw needs of a scene: build(world) and camera(w, h)."""
+
+    def __init__(self, seed):
+        self.seed = seed
+        rng = np.random.RandomState(7000 + seed)
+        self.eye = rng.uniform(-11, 11, 3)
+        self.eye[1] = abs(self.eye[1]) + 1.0
+        self.to, self.fov = rng.uniform(-2, 2, 3), float(rng.uniform(0.5, 1.6))
+
+    def build(self, w):
+        mixed_world(w, np.random.RandomState(self.seed), True, bool(self.seed % 2))
+        return w
+
+    def camera(self, hsize, vsize):
+        from raytracer_amd import builder as B
+        return B.Camera(hsize, vsize, self.fov, tuple(self.eye), tuple(self.to), (0, 1, 0))
+
+
+def run_parts(seed, log=print):
+    """A random frame through rt_render_device as 1 part and as n interleaved parts of random stripe height: same bytes."""
+    from raytracer_amd import tiles
+    from test_gpu_parity import Raw
+    rng = np.random.RandomState(9000 + seed)
+    size = (int(rng.randint(9, 400)), int(rng.randint(5, 300)))
+    raw = Raw(_FuzzScene(seed), size)
+    full, ids, st = raw.render()
+    n, tile_h = int(rng.randint(2, 9)), int(rng.choice([1, 2, 3, 8, 16]))
+    canvas, idc, primary = np.full_like(full, np.nan), np.full_like(ids, -9), 0
+    for p in range(n):
+        rows = tiles.part_rows(size[1], tile_h, n, p)
+        rgb, oid, s = raw.render(tile_h=tile_h, n_parts=n, part=p)
+        if len(rows):
+            canvas[rows], idc[rows] = rgb[: len(rows)], oid[: len(rows)]
+        primary += s.primary
+    ok = np.array_equal(canvas.view(np.uint32), full.view(np.uint32)) and np.array_equal(idc, ids) and primary == st.primary
+    log(f"parts seed {seed} {size[0]}x{size[1]} n {n} tile_h {tile_h}: {'ok' if ok else 'FAIL'}")
+    return 0 if ok else 1
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "parts":
+        first, count = int(sys.argv[2]), int(sys.argv[3])
+        bad = sum(run_parts(seed, log=lambda m: print(m, flush=True)) for seed in range(first, first + count))
+        print("failures:", bad)
+        sys.exit(1 if bad else 0)
     if len(sys.argv) > 1 and sys.argv[1] == "frames":
         first, count = int(sys.argv[2]), int(sys.argv[3])
         bad = sum(run_frame(seed, log=lambda m: print(m, flush=True)) for seed in range(first, first + count))
