@@ -32,6 +32,7 @@ from raytracer_amd.obj import parse_obj  # noqa: E402
 from raytracer_amd.scene import Scene  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+VALU_PEAK_NO_FMA = 39.3  # TFLOP/s: 256 CUs x 64 lanes x 2.4 GHz, one mul or add per lane per cycle (no FMA: SURVEY.md Q11)
 
 
 def load_workload(name: str):
@@ -69,6 +70,12 @@ def main():
     json_fd = os.dup(1)
     os.dup2(2, 1)
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` by itself: start one rank per GPU (fresh child processes, nothing here has
+        # touched the GPU yet) and relay rank 0's JSON line; under torchrun the ranks already exist
+        from raytracer_amd.launch import launch_ranks
+        os.dup2(json_fd, 1)
+        raise SystemExit(launch_ranks(args.gpus, [sys.executable, os.path.abspath(__file__), *sys.argv[1:]]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -94,7 +101,6 @@ def main():
     hw = scene.build(host.new_world(local_rank))
     ctx, dscene = hw.device_scene()
     setup_s = time.time() - t0
-    n_lights = int(hw.flatten().n_lights)
     lib = host.hip_lib()
     rcam = hw.rt_camera(cam)
     opts = abi.RtRenderOptions(abi.RT_JITTER_COUNTER, 0.5, 1, args.tile_h, world, rank, 0)
@@ -144,13 +150,13 @@ def main():
         mine_rows = torch.from_numpy(tiles.part_rows(cam.vsize, args.tile_h, world, rank)).to(dev)
         if not torch.equal(pipe.canvas[last].index_select(0, mine_rows), pipe.local[last][: len(mine_rows)]):
             raise RuntimeError("gathered canvas does not hold this rank's rows")
-    tot = torch.tensor([elapsed, float(my_rays)], dtype=torch.float64, device=dev)
+    tot = torch.tensor([elapsed, float(my_rays), float(cst.rays_reference)], dtype=torch.float64, device=dev)
     if gather:
         tmax = tot.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         elapsed = float(tmax[0])
-    total_rays = float(tot[1])
+    total_rays, ref_rays = float(tot[1]), float(tot[2])
     ms_per_step = elapsed / args.steps * 1e3
     value = total_rays / (ms_per_step * 1e-3) / 1e6
 
@@ -162,33 +168,78 @@ def main():
                                    C.c_void_p(stream.cuda_stream), C.byref(st)), "rt_render_device(stats)")
         kms.append(st.kernel_ms)
     kernel_ms = float(np.mean(kms))
-    # algorithmic bytes and flops of one launch (SURVEY.md §8d / DESIGN.md "Measurement"): per-unit figures
-    # times the units the instrumented launch counted
-    alg_bytes = (cst.node_visits * 32 + cst.aux_tests * 32 + cst.tri_tests * 36 + cst.shape_tests * 32
-                 + cst.shaded_hits * 36 + cst.node_xforms * 48 + rows * cam.hsize * 12)
+    # Work of one launch from the instrumented kernel (RT_RENDER_COUNT_WORK), priced with the per-unit figures of
+    # SURVEY.md §8(d) / DESIGN.md "Measurement".  These bytes are what the algorithm reads per lane; the walk fetches
+    # wave-uniform records once per wave and the scene is cache resident, so they are NOT HBM traffic: they are reported
+    # as `algorithmic` (cache-level), never as the roofline fraction.
+    alg_bytes = (cst.node_visits * 32 + cst.tri_tests * 36 + cst.shaded_hits * 36 + cst.node_xforms * 48
+                 + rows * cam.hsize * 12)
     alg_flops = (cst.node_visits * 12 + cst.node_xforms * 33 + cst.aux_tests * 18 + cst.tri_tests * 24
                  + cst.shape_tests * 30 + cst.shaded_hits * 140 + cst.primary * 36)
-    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-    # HBM traffic per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE doubled: gfx950
-    # counts 64 B per 128-B request, MI355X_MICROARCH.md "HBM"); null when no pass matches this workload
-    traffic = None
+    ksec = kernel_ms * 1e-3
+    valu_tflops = alg_flops / ksec / 1e12
+    # HBM bytes per launch: the rocprofv3 PMC passes of this same command committed under profiles/ (FETCH_SIZE
+    # doubled: gfx950 counts 64 B per 128-B request, MI355X_MICROARCH.md "HBM"); null when no pass matches this
+    # workload and kernel (bench.py cannot run the profiler on itself)
+    traffic, traffic_src = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         with open(tpath) as f:
             tj = json.load(f)
         if tj.get("workload") == f"{args.workload}.yaml {cam.hsize}x{cam.vsize}" and tj.get("parts") == world:
             traffic = int(2 * tj["fetch_kb"] * 1024 + tj["write_kb"] * 1024)
-    roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                "kernel": "k_render_jobs", "kernel_ms": round(kernel_ms, 3), "algorithmic_bytes": int(alg_bytes),
-                "note": "algorithmic bytes are served by L1/L2 (scene is cache resident); see traffic for HBM bytes",
-                "valu": {"achieved": round(alg_flops / (kernel_ms * 1e-3) / 1e12, 3), "unit": "TFLOP/s",
-                         "peak_fma_packed": 157.3, "peak_no_fma_scalar": 39.3,
-                         "frac_of_no_fma_peak": round(alg_flops / (kernel_ms * 1e-3) / 1e12 / 39.3, 5),
-                         "algorithmic_flops": int(alg_flops)},
-                "counters": {"node_visits": cst.node_visits, "aux_box_tests": cst.aux_tests, "tri_tests": cst.tri_tests,
-                             "shape_tests": cst.shape_tests, "shaded_hits": cst.shaded_hits,
-                             "node_xforms": cst.node_xforms}}
+            traffic_src = tj.get("source", "profiles/traffic.json")
+    hbm_gbs = traffic / ksec / 1e9 if traffic else None
+    hbm_frac = hbm_gbs / HBM_PEAK_GBS if traffic else 0.0
+    valu_frac = valu_tflops / VALU_PEAK_NO_FMA
+    # the kernel is bound by instruction issue and memory latency (lane utilisation, dependent fetches), far below both
+    # roofs; the line names the nearer one
+    if hbm_frac >= valu_frac:
+        roofline = {"bound": "hbm", "achieved": round(hbm_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(hbm_frac, 5)}
+    else:
+        roofline = {"bound": "valu", "achieved": round(valu_tflops, 3), "peak": VALU_PEAK_NO_FMA, "unit": "TFLOP/s",
+                    "frac": round(valu_frac, 5)}
+    roofline.update({
+        "traffic": traffic, "traffic_source": traffic_src,
+        "kernel": "k_render_jobs", "kernel_ms": round(kernel_ms, 3),
+        "limiter": "issue/latency: divergent traversal, see profiles/ (SQ passes) and DESIGN.md section 4",
+        "hbm": {"achieved": round(hbm_gbs, 2) if traffic else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(hbm_frac, 5) if traffic else None},
+        "valu": {"achieved": round(valu_tflops, 3), "unit": "TFLOP/s", "peak_no_fma_scalar": VALU_PEAK_NO_FMA,
+                 "peak_fma_packed": 157.3, "frac": round(valu_frac, 5), "algorithmic_flops": int(alg_flops),
+                 "note": "bit-exact parity forbids FMA contraction (SURVEY.md Q11): 39.3 TFLOP/s is the ceiling of "
+                         "scalar-lane mul/add on 256 CUs at 2.4 GHz"},
+        "algorithmic": {"bytes": int(alg_bytes), "gbps": round(alg_bytes / ksec / 1e9, 2),
+                        "frac_of_hbm_peak": round(alg_bytes / ksec / 1e9 / HBM_PEAK_GBS, 5),
+                        "note": "SURVEY.md 8(d) units only (node visits 32 B, triangle tests 36 B, hit normals 36 B, "
+                                "node transforms 48 B, output 12 B/pixel), per lane: served by scalar loads and "
+                                "L1/L2, not by HBM"},
+        "counters": {"node_visits": cst.node_visits, "aux_box_tests": cst.aux_tests, "tri_tests": cst.tri_tests,
+                     "shape_tests": cst.shape_tests, "shaded_hits": cst.shaded_hits, "node_xforms": cst.node_xforms}})
+
+    # the same frame through rt_render: host buffers out (pageable memory), the PCIe-inclusive figure (never `value`)
+    host_frame_ms = None
+    eighths_ms = None
+    if world == 1 and rank == 0:
+        hbuf = np.empty((cam.vsize, cam.hsize, 3), dtype=np.float32)
+        fopts = abi.RtRenderOptions(abi.RT_JITTER_COUNTER, 0.5, 1, 1, 1, 0, 0)
+        hms = []
+        for _ in range(4):
+            th = time.perf_counter()
+            check(lib.rt_render(ctx, dscene, C.byref(rcam), C.byref(fopts), hbuf.ctypes.data, None, None), "rt_render")
+            hms.append((time.perf_counter() - th) * 1e3)
+        host_frame_ms = round(min(hms[1:]), 3)
+        # strong-scaling preview: kernel time of each eighth of the frame (what each of 8 GPUs would render)
+        eighths_ms = []
+        for p in range(8):
+            po = abi.RtRenderOptions(abi.RT_JITTER_COUNTER, 0.5, 1, args.tile_h, 8, p, 0)
+            best = 1e9
+            for _ in range(3):
+                check(lib.rt_render_device(ctx, dscene, C.byref(rcam), C.byref(po), local.data_ptr(), None,
+                                           C.c_void_p(stream.cuda_stream), C.byref(st)), "rt_render_device(part)")
+                best = min(best, st.kernel_ms)
+            eighths_ms.append(round(best, 3))
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -215,9 +266,10 @@ def main():
             "config": {"workload": f"{args.workload}.yaml {cam.hsize}x{cam.vsize} recursion_limit 4 {mesh_label}".strip(),
                        "tile_h": args.tile_h, "parts": world, "rays_per_frame": int(total_rays),
                        "rays_traced": int(total_rays),
-                       # the reference re-traces secondary rays once per light: equal with one light
-                       "rays_reference": int(total_rays) if n_lights == 1 else None,
-                       "frame_ms": round(ms_per_step, 3), "scene_setup_s": round(setup_s, 1)},
+                       # what the reference would cast: it re-traces secondary rays once per light
+                       "rays_reference": int(ref_rays),
+                       "frame_ms": round(ms_per_step, 3), "host_frame_ms": host_frame_ms,
+                       "eighths_kernel_ms": eighths_ms, "scene_setup_s": round(setup_s, 2)},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         sys.stdout.flush()

@@ -233,6 +233,10 @@ typedef struct {
   uint64_t aux_tests;  /* box tests against the library's auxiliary BVHs */
   double kernel_ms;    /* device time of the render kernel(s), HIP events on the render stream */
   double total_ms;     /* wall time of the call */
+  /* With RT_RENDER_COUNT_WORK: the rays the REFERENCE casts for the same pixels.  It re-traces every secondary ray
+   * once per light (src/world.rs:66-86) where the device traces it once and weights it; equal to
+   * primary+shadow+reflect+refract for worlds with one light. */
+  uint64_t rays_reference;
 } RtStats;
 
 typedef struct RtContext RtContext;         /* one GPU */
@@ -273,9 +277,24 @@ int rt_render(RtContext*, const RtDeviceScene*, const RtCamera*, const RtRenderO
  * `stream` is a hipStream_t (NULL = the context's own stream, NOT the legacy null stream: a caller whose
  * other work is on the null stream, e.g. torch's default stream, must create a stream, pass it here and
  * run that other work on it, or synchronise). The call is asynchronous unless
- * stats != NULL (then it synchronises the stream to read the counters and event times). */
+ * stats != NULL (then it synchronises the stream to read the counters and event times).
+ *
+ * Launches in flight: every call takes its own counter block and work queue from a ring of 8 in the context, so
+ * up to 8 asynchronous launches may be in flight on any mix of streams; the 9th waits (stream-side) for the 1st.
+ * The calls themselves are still made from one host thread at a time (a context is single-threaded).
+ *
+ * Overflow of a per-ray intersection list (RT_E_OVERFLOW): a synchronous call (stats != NULL, rt_render,
+ * rt_color_at) returns it itself.  An asynchronous call cannot: its overflow is kept in the context and returned by the
+ * NEXT synchronising call on that context, or by rt_check.  A caller that renders asynchronously must call rt_check
+ * (or a synchronous entry point) before trusting the frames rendered since the last check. */
 int rt_render_device(RtContext*, const RtDeviceScene*, const RtCamera*, const RtRenderOptions*, float* d_out_rgb,
                      RtAux* d_aux, void* stream, RtStats* stats);
+
+/* Synchronises `stream` (NULL: every stream of the context's GPU) and returns RT_E_OVERFLOW if any launch on this
+ * context since the last synchronising call overflowed a per-ray list, RT_OK otherwise; clears the condition.
+ * Where the reference's Camera::render would simply have returned (its Intersections list is unbounded,
+ * src/intersections.rs:66-73), this is how the asynchronous path reports the device limit. */
+int rt_check(RtContext*, void* stream);
 
 /* World::color_at(ray, remaining) (src/world.rs:91-99) and Intersections::hit()
  * (src/intersections.rs:94-96) for n caller-supplied rays (host pointers): origins/directions

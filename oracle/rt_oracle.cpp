@@ -1712,7 +1712,8 @@ int orc_render(RtbWorld* w, const RtbCamera* cam, const RtbRenderOptions* opts, 
   Camera c;
   if (!make_camera(cam, &c)) return fail(w, "camera transform is not invertible");
   w->freeze();
-  int threads = opts && opts->threads > 0 ? opts->threads : (int)std::thread::hardware_concurrency();
+  // default: the box's CPU share, not the machine (hardware_concurrency() reports every core of the host there)
+  int threads = opts && opts->threads > 0 ? opts->threads : (int)std::min(16u, std::thread::hardware_concurrency());
   if (threads < 1) threads = 1;
   int row_begin = opts ? opts->row_begin : 0;
   int row_end = (opts && opts->row_end > 0) ? opts->row_end : (int)c.vsize;
@@ -1774,25 +1775,42 @@ int orc_render(RtbWorld* w, const RtbCamera* cam, const RtbRenderOptions* opts, 
 int orc_color_at(RtbWorld* w, const RtbRenderOptions* opts, const float* origins, const float* directions, int n,
                  int remaining, float* out_rgb, float* hit_t, int32_t* hit_id, float* hit_uv) {
   w->freeze();
-  setup_ctx(w, opts);
-  for (int i = 0; i < n; i++) {
-    Ray r{point(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]),
-          vector(directions[3 * i], directions[3 * i + 1], directions[3 * i + 2])};
-    g_ctx.pixel = (uint32_t)i;
-    g_ctx.path = 1;
-    Intersection ph;
-    Tuple col = w->color_at(r, remaining, &ph);
-    if (out_rgb) {
-      out_rgb[3 * i] = col.v[0];
-      out_rgb[3 * i + 1] = col.v[1];
-      out_rgb[3 * i + 2] = col.v[2];
+  // rays are independent (the jitter key is the ray index): worker threads take chunks of 64
+  int threads = opts && opts->threads > 0 ? opts->threads : (int)std::min(16u, std::thread::hardware_concurrency());
+  if (threads < 1 || n < 256 || (opts && opts->jitter_mode == RTB_JITTER_SEQUENCE)) threads = 1;  // the cycling fake is one sequence
+  std::atomic<int> next{0};
+  auto worker = [&]() {
+    setup_ctx(w, opts);
+    for (;;) {
+      const int b = next.fetch_add(64);
+      if (b >= n) break;
+      for (int i = b; i < std::min(n, b + 64); i++) {
+        Ray r{point(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]),
+              vector(directions[3 * i], directions[3 * i + 1], directions[3 * i + 2])};
+        g_ctx.pixel = (uint32_t)i;
+        g_ctx.path = 1;
+        Intersection ph;
+        Tuple col = w->color_at(r, remaining, &ph);
+        if (out_rgb) {
+          out_rgb[3 * i] = col.v[0];
+          out_rgb[3 * i + 1] = col.v[1];
+          out_rgb[3 * i + 2] = col.v[2];
+        }
+        if (hit_t) hit_t[i] = ph.t;
+        if (hit_id) hit_id[i] = ph.shape ? ph.shape->rank : -1;
+        if (hit_uv) {
+          hit_uv[2 * i] = ph.shape ? ph.u : 0.f;
+          hit_uv[2 * i + 1] = ph.shape ? ph.v : 0.f;
+        }
+      }
     }
-    if (hit_t) hit_t[i] = ph.t;
-    if (hit_id) hit_id[i] = ph.shape ? ph.shape->rank : -1;
-    if (hit_uv) {
-      hit_uv[2 * i] = ph.shape ? ph.u : 0.f;
-      hit_uv[2 * i + 1] = ph.shape ? ph.v : 0.f;
-    }
+  };
+  if (threads == 1) {
+    worker();
+  } else {
+    std::vector<std::thread> pool;
+    for (int i = 0; i < threads; i++) pool.emplace_back(worker);
+    for (auto& t : pool) t.join();
   }
   return 0;
 }

@@ -80,7 +80,8 @@ class RtStats(C.Structure):
     _fields_ = [("primary", C.c_uint64), ("shadow", C.c_uint64), ("reflect", C.c_uint64), ("refract", C.c_uint64),
                 ("overflow", C.c_uint64), ("node_visits", C.c_uint64), ("tri_tests", C.c_uint64),
                 ("shape_tests", C.c_uint64), ("shaded_hits", C.c_uint64), ("node_xforms", C.c_uint64),
-                ("aux_tests", C.c_uint64), ("kernel_ms", C.c_double), ("total_ms", C.c_double)]
+                ("aux_tests", C.c_uint64), ("kernel_ms", C.c_double), ("total_ms", C.c_double),
+                ("rays_reference", C.c_uint64)]
 
 
 class RtAccelView(C.Structure):
@@ -96,7 +97,7 @@ AUX_TRI = np.dtype([("p1", "<f4", 3), ("shape", "<u4"), ("e1", "<f4", 3), ("owne
 assert AUX_NODE.itemsize == 80 and AUX_TRI.itemsize == 48
 
 EXPORTS = ["rt_accel_build", "rt_accel_free", "rt_abi_version", "rt_context_create", "rt_context_destroy", "rt_last_error", "rt_scene_create",
-           "rt_scene_destroy", "rt_part_rows", "rt_render", "rt_render_device", "rt_color_at"]
+           "rt_scene_destroy", "rt_part_rows", "rt_render", "rt_render_device", "rt_check", "rt_color_at"]
 
 
 def declare(lib: C.CDLL) -> None:
@@ -116,6 +117,7 @@ def declare(lib: C.CDLL) -> None:
     lib.rt_render_device.restype = C.c_int
     lib.rt_render_device.argtypes = [P, P, C.POINTER(RtCamera), C.POINTER(RtRenderOptions), P, C.POINTER(RtAux), P,
                                      C.POINTER(RtStats)]
+    lib.rt_check.restype, lib.rt_check.argtypes = C.c_int, [P, P]
     lib.rt_color_at.restype = C.c_int
     lib.rt_color_at.argtypes = [P, P, C.POINTER(RtRenderOptions), P, P, C.c_uint32, C.c_uint32, P, P, P, P,
                                 C.POINTER(RtStats)]

@@ -73,6 +73,10 @@ struct Counters {
   // work counters (only maintained by the COUNT instantiations; bench roofline)
   uint32_t node_visits, tri_tests, shape_tests, shaded, xforms, aux_tests;
   uint32_t work_shadow, work_collect;  // COUNT only: tests spent in shadow rays / n1-n2 collect passes
+  // COUNT only: the rays the REFERENCE would have cast for the same pixels.  It re-traces every secondary ray once
+  // per light (world.rs:66-86) where the device traces it once and weights it, so a ray `k` levels below
+  // the primary stands for n_lights^k reference rays.  Equal to primary+shadow+reflect+refract with one light.
+  uint32_t ref_rays;
 #ifdef RT_PHASE_TIMERS
   uint32_t t_iters, t_load;
   uint32_t u[8];  // lane / wave step counts: aux node, aux leaf, walk visit, walk shapes
@@ -114,6 +118,7 @@ struct Scene {
   uint32_t n_shapes, n_nodes, n_csg_roots, n_lights, n_loose, recursion_limit;
   uint32_t flags;  // RT_RENDER_*
   uint32_t props;  // RT_SCENE_* (derived by rt_scene_create)
+  unsigned long long* sticky;  // the context's overflow word: launches add to it, synchronising calls read and clear it
 };
 
 // The scene tables are never written while a kernel runs.  Reading them through the constant address space tells the
@@ -1158,6 +1163,12 @@ __device__ __forceinline__ float counter_jitter(uint64_t seed, uint32_t pixel, u
   return (float)(h >> 8) * (1.0f / 16777216.0f);
 }
 
+// n_lights ^ depth: how many times the reference traces a ray `depth` levels below the primary (Q4)
+__device__ __forceinline__ uint32_t ref_multiplicity(uint32_t n_lights, uint32_t depth) {
+  uint32_t m = 1u;
+  for (uint32_t k = 0; k < depth; k++) m *= n_lights;
+  return m;
+}
 struct RenderParams {
   uint32_t jitter_mode;
   float jitter_value;
@@ -1357,6 +1368,7 @@ __device__ inline void integrate(const Scene& sc, const RenderParams& rp, const 
           if (want < n_items && src.start((uint32_t)want, primary)) {
             item = (uint32_t)want;
             cn.primary++;
+            if (COUNT) cn.ref_rays++;
             pk_st3(pk, PK_RESULT, v3(0.f, 0.f, 0.f));
             pk_st3(pk, PK_SRAY_O, primary.o);
             pk_st3(pk, PK_SRAY_D, primary.d);
@@ -1546,6 +1558,7 @@ __device__ inline void integrate(const Scene& sc, const RenderParams& rp, const 
           distance = magnitude(v);
           tray = Ray{over_point, v / distance};
           cn.shadow++;
+          if (COUNT) cn.ref_rays += ref_multiplicity(sc.n_lights, remaining0 - remaining);
           shadow_tF = __builtin_inff();
           shadow_sF = -1;
           job = (sc.props & RT_SCENE_SHADOW_TWO_PASS) ? JOB_SHADOW_F : JOB_SHADOW;
@@ -1613,6 +1626,7 @@ __device__ inline void integrate(const Scene& sc, const RenderParams& rp, const 
               const V3 under_point = point - 1e-4f * normalv;
               stack[sp++] = PendingRay{Ray{under_point, direction}, w, remaining - 1u, path * 2u + 1u};
               cn.refract++;
+              if (COUNT) cn.ref_rays += ref_multiplicity(sc.n_lights, remaining0 - remaining + 1u);
             } else {
               cn.overflow++;
             }
@@ -1624,6 +1638,7 @@ __device__ inline void integrate(const Scene& sc, const RenderParams& rp, const 
             const V3 over_point = point + 1e-4f * normalv;
             stack[sp++] = PendingRay{Ray{over_point, reflect(sray.d, normalv)}, w, remaining - 1u, path * 2u};
             cn.reflect++;
+            if (COUNT) cn.ref_rays += ref_multiplicity(sc.n_lights, remaining0 - remaining + 1u);
           } else {
             cn.overflow++;
           }
@@ -1684,11 +1699,12 @@ __device__ __forceinline__ Hit direct_closest(const Scene& sc, const Ray& ray, C
 }
 // World::is_shadowed (world.rs:101-111), see Sink::init_any_shadow for the two equivalent searches
 template <bool COUNT>
-__device__ __forceinline__ bool direct_is_shadowed(const Scene& sc, V3 light_position, V3 p, Counters& cn) {
+__device__ __forceinline__ bool direct_is_shadowed(const Scene& sc, V3 light_position, V3 p, Counters& cn, uint32_t mult) {
   V3 v = light_position - p;
   float distance = magnitude(v);
   V3 direction = v / distance;
   cn.shadow++;
+  if (COUNT) cn.ref_rays += mult;
   Sink sink;
   if (sc.props & RT_SCENE_HAS_NOSHADOW) {
     sink.init_closest();
@@ -1720,6 +1736,7 @@ __device__ __forceinline__ V3 color_at_direct(const Scene& sc, const RenderParam
     }
     if (hit.shape < 0) continue;
     if (COUNT) cn.shaded++;
+    const uint32_t mult = COUNT ? ref_multiplicity(sc.n_lights, remaining0 - pr.remaining) : 0u;
     // ---- Computations::prepare (intersections.rs:121-139) ----
     const u4n RT_CONST_AS* raw = cst(reinterpret_cast<const u4n*>(sc.shapes + hit.shape));
     u4n w0 = raw[0], w1 = raw[1];
@@ -1768,7 +1785,7 @@ __device__ __forceinline__ V3 color_at_direct(const Scene& sc, const RenderParam
       V3 surface;
       if (L.kind == RT_LIGHT_POINT) {
         V3 lpos = v3(L.position[0], L.position[1], L.position[2]);
-        float intensity = direct_is_shadowed<COUNT>(sc, lpos, over_point, cn) ? 0.f : 1.f;  // lights.rs:50-56
+        float intensity = direct_is_shadowed<COUNT>(sc, lpos, over_point, cn, mult) ? 0.f : 1.f;  // lights.rs:50-56
         V3 diffuse = v3(0.f, 0.f, 0.f), specular = v3(0.f, 0.f, 0.f);
         phong_sample(lpos, over_point, eyev, normalv, effective, lcol, m_diffuse, m_specular, m_shininess, diffuse,
                      specular);
@@ -1779,7 +1796,7 @@ __device__ __forceinline__ V3 color_at_direct(const Scene& sc, const RenderParam
         for (uint32_t u = 0; u < L.usteps; u++)
           for (uint32_t v = 0; v < L.vsteps; v++) {
             V3 lpos = point_on_light(L, li, u, v, 0u, rp, pixel, pr.path);
-            if (!direct_is_shadowed<COUNT>(sc, lpos, over_point, cn)) total += 1.f;
+            if (!direct_is_shadowed<COUNT>(sc, lpos, over_point, cn, mult)) total += 1.f;
           }
         float nb = (float)(L.usteps * L.vsteps);
         float intensity = total / nb;
@@ -1849,6 +1866,7 @@ __device__ __forceinline__ V3 color_at_direct(const Scene& sc, const RenderParam
         if (sp < RT_MAX_RAY_STACK) {
           stack[sp++] = PendingRay{Ray{under_point, direction}, w, pr.remaining - 1u, pr.path * 2u + 1u};
           cn.refract++;
+          if (COUNT) cn.ref_rays += mult * sc.n_lights;
         } else {
           cn.overflow++;
         }
@@ -1859,6 +1877,7 @@ __device__ __forceinline__ V3 color_at_direct(const Scene& sc, const RenderParam
       if (sp < RT_MAX_RAY_STACK) {
         stack[sp++] = PendingRay{Ray{over_point, reflectv}, w, pr.remaining - 1u, pr.path * 2u};
         cn.reflect++;
+        if (COUNT) cn.ref_rays += mult * sc.n_lights;
       } else {
         cn.overflow++;
       }

@@ -19,11 +19,7 @@ using namespace rtd;
 
 namespace {
 
-#ifdef RT_PHASE_TIMERS
-#define RT_N_COUNTERS 32
-#else
-#define RT_N_COUNTERS 16
-#endif
+#define RT_N_COUNTERS 32  // u64 slots per counter block: 0-10 RtStats, 11-14 and 16-23 diagnostics, 15 work queue, 24 reference rays
 #ifndef RT_BLOCKS_PER_CU
 #define RT_BLOCKS_PER_CU 4  // 256-thread blocks resident per CU at four waves per SIMD
 #endif
@@ -37,11 +33,11 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
 }
-__device__ __forceinline__ void flush_counters(const Counters& cn, unsigned long long* g) {
+__device__ __forceinline__ void flush_counters(const Counters& cn, unsigned long long* g, unsigned long long* sticky) {
   uint32_t a = wave_sum(cn.primary), b = wave_sum(cn.shadow), c = wave_sum(cn.reflect), d = wave_sum(cn.refract),
            e = wave_sum(cn.overflow);
   uint32_t w0 = wave_sum(cn.node_visits), w1 = wave_sum(cn.tri_tests), w2 = wave_sum(cn.shape_tests),
-           w3 = wave_sum(cn.shaded), w4 = wave_sum(cn.xforms), w5 = wave_sum(cn.aux_tests);
+           w3 = wave_sum(cn.shaded), w4 = wave_sum(cn.xforms), w5 = wave_sum(cn.aux_tests), w6 = wave_sum(cn.ref_rays);
 #ifdef RT_PHASE_TIMERS
   for (int k = 0; k < 8; k++) {
     uint32_t v = wave_sum(cn.u[k]);
@@ -61,11 +57,15 @@ __device__ __forceinline__ void flush_counters(const Counters& cn, unsigned long
     if (w3) atomicAdd(g + 8, (unsigned long long)w3);
     if (w4) atomicAdd(g + 9, (unsigned long long)w4);
     if (w5) atomicAdd(g + 10, (unsigned long long)w5);
+    if (w6) atomicAdd(g + 24, (unsigned long long)w6);
     if (a) atomicAdd(g + 0, (unsigned long long)a);
     if (b) atomicAdd(g + 1, (unsigned long long)b);
     if (c) atomicAdd(g + 2, (unsigned long long)c);
     if (d) atomicAdd(g + 3, (unsigned long long)d);
-    if (e) atomicAdd(g + 4, (unsigned long long)e);
+    if (e) {
+      atomicAdd(g + 4, (unsigned long long)e);
+      atomicAdd(sticky, (unsigned long long)e);  // survives the launch: reported by the next synchronising call (rt_check)
+    }
   }
 }
 
@@ -175,7 +175,7 @@ void k_render_jobs(Scene sc, RtCamera cam, RenderParams rp, PartInfo part, Pixel
 #ifdef RT_PHASE_TIMERS
   if ((threadIdx.x & 63) == 0) atomicAdd(counters + 14, (unsigned long long)(__builtin_readcyclecounter() - t_pixel0));
 #endif
-  flush_counters(cn, counters);
+  flush_counters(cn, counters, sc.sticky);
 }
 // the direct integrator is force-inlined so that the register budget applies to it (as a called function it took 248
 // VGPRs whatever the kernel asked for: soft_shadows 4K 20.9 -> 12.4 ms at four waves per SIMD; 5: same, 6: slower)
@@ -196,6 +196,7 @@ void k_render_direct(Scene sc, RtCamera cam, RenderParams rp, PartInfo part, Pix
   if (px < cam.hsize && ly < part.rows) {
     const uint32_t py = (ly / part.tile_h) * (part.n_parts * part.tile_h) + part.part * part.tile_h + (ly % part.tile_h);
     cn.primary = 1;
+    if (COUNT) cn.ref_rays = 1;
     Hit ph;
     V3 col = color_at_direct<COUNT>(sc, rp, ray_for_pixel(cam, px, py), sc.recursion_limit, py * cam.hsize + px, cn, &ph);
     ph.shape = reported_shape(sc, ph.shape);
@@ -204,7 +205,7 @@ void k_render_direct(Scene sc, RtCamera cam, RenderParams rp, PartInfo part, Pix
                         (float)(cn.node_visits + cn.aux_tests + cn.tri_tests + cn.shape_tests), (float)cn.work_shadow,
                         (float)cn.work_collect);
   }
-  flush_counters(cn, counters);
+  flush_counters(cn, counters, sc.sticky);
 }
 
 // World::color_at for caller-supplied rays (world.rs:91-99).
@@ -250,7 +251,7 @@ void k_color_at_jobs(Scene sc, RenderParams rp, RayOut o, uint32_t remaining, un
   RaySource src{o};
   Counters cn = {};
   integrate<COUNT, CULL>(sc, rp, src, remaining, counters + RT_QUEUE_SLOT, cn);
-  flush_counters(cn, counters);
+  flush_counters(cn, counters, sc.sticky);
 }
 __global__ __launch_bounds__(RT_BLOCK) void k_color_at_direct(Scene sc, RenderParams rp, RayOut o, uint32_t remaining,
                                                              unsigned long long* counters) {
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_color_at_direct(Scene sc, RenderPa
     ph.shape = reported_shape(sc, ph.shape);
     write_ray_hit(o, i, ph);
   }
-  flush_counters(cn, counters);
+  flush_counters(cn, counters, sc.sticky);
 }
 
 }  // namespace
@@ -274,13 +275,22 @@ __global__ __launch_bounds__(RT_BLOCK) void k_color_at_direct(Scene sc, RenderPa
 // =========================================================================================
 // host side of the ABI
 // =========================================================================================
+#define RT_RING 8       // counter blocks of the asynchronous launches
 #define RT_MAX_BANDS 4  // rt_render renders a full frame as up to this many row bands, copying each back while the next renders
 struct RtContext {
   int device = 0;
   hipStream_t stream = nullptr, copy_stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipEvent_t ev_band[RT_MAX_BANDS] = {nullptr, nullptr, nullptr, nullptr};
-  unsigned long long* d_counters = nullptr;  // RT_N_COUNTERS slots for rt_render_device, then one block per band
+  // Counter blocks (RT_N_COUNTERS slots each; one slot of a block is the launch's work queue).  Every launch of
+  // rt_render_device / rt_color_at takes the next block of a ring of RT_RING, so launches in flight on different
+  // streams never share a queue; before a block is reused the new stream waits for the launch that used it last.
+  // Then one block per band of rt_render, then the sticky overflow word.
+  unsigned long long* d_counters = nullptr;
+  hipEvent_t ev_ring[RT_RING] = {};
+  bool ring_used[RT_RING] = {};
+  unsigned ring_next = 0;
+  unsigned long long* d_sticky = nullptr;
   uint32_t n_cus = 256;
   // frame buffers of rt_render, kept between calls (grow only)
   void* d_frame[4] = {nullptr, nullptr, nullptr, nullptr};  // rgb, mask, object id, hit t
@@ -445,6 +455,7 @@ int read_stats(RtContext* ctx, hipStream_t stream, RtStats* stats, double total_
   stats->shaded_hits = h[8];
   stats->node_xforms = h[9];
   stats->aux_tests = h[10];
+  stats->rays_reference = h[24];
 #ifdef RT_PHASE_TIMERS
   {
     const char* nm[4] = {"aux node", "aux leaf", "walk visit", "walk shape"};
@@ -457,6 +468,34 @@ int read_stats(RtContext* ctx, hipStream_t stream, RtStats* stats, double total_
   stats->kernel_ms = ms;
   stats->total_ms = total_ms;
   return RT_OK;
+}
+
+// The counter block of the next asynchronous launch on `stream` (see RtContext::d_counters).
+int ring_acquire(RtContext* ctx, hipStream_t stream, unsigned* slot_out, unsigned long long** block_out) {
+  const unsigned slot = ctx->ring_next++ % RT_RING;
+  if (ctx->ring_used[slot]) HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->ev_ring[slot], 0));
+  *slot_out = slot;
+  *block_out = ctx->d_counters + (size_t)slot * RT_N_COUNTERS;
+  return RT_OK;
+}
+int ring_release(RtContext* ctx, hipStream_t stream, unsigned slot) {
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_ring[slot], stream));
+  ctx->ring_used[slot] = true;
+  return RT_OK;
+}
+// After `stream` has been synchronised: did any launch since the last check overflow a per-ray list?  Reads and clears
+// the context's sticky word, so an overflow in an asynchronous call (no stats) is reported by the next call that
+// synchronises, never lost.
+int take_sticky_overflow(RtContext* ctx, hipStream_t stream) {
+  unsigned long long v = 0;
+  HIP_TRY(ctx, hipMemcpyAsync(&v, ctx->d_sticky, sizeof(v), hipMemcpyDeviceToHost, stream));
+  HIP_TRY(ctx, hipStreamSynchronize(stream));
+  if (!v) return RT_OK;
+  HIP_TRY(ctx, hipMemsetAsync(ctx->d_sticky, 0, sizeof(v), stream));
+  HIP_TRY(ctx, hipStreamSynchronize(stream));
+  return fail(ctx, RT_E_OVERFLOW,
+              "per-ray intersection list overflow (" + std::to_string(v) + " rays) in this call or in an earlier asynchronous "
+              "call on this context: those images are invalid");
 }
 
 }  // namespace
@@ -472,7 +511,7 @@ int rt_context_create(int device, RtContext** out) {
   c->device = device;
   auto bail = [&](hipError_t e, const char* what) {
     std::fprintf(stderr, "rt_context_create: %s: %s\n", what, hipGetErrorString(e));
-    delete c;
+    rt_context_destroy(c);
     return RT_E_DEVICE;
   };
   hipError_t e;
@@ -486,8 +525,14 @@ int rt_context_create(int device, RtContext** out) {
   if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
   if ((e = hipEventCreate(&c->ev0)) != hipSuccess) return bail(e, "hipEventCreate");
   if ((e = hipEventCreate(&c->ev1)) != hipSuccess) return bail(e, "hipEventCreate");
-  if ((e = hipMalloc((void**)&c->d_counters, (1 + RT_MAX_BANDS) * RT_N_COUNTERS * sizeof(unsigned long long))) != hipSuccess)
-    return bail(e, "hipMalloc");
+  {
+    const size_t words = (size_t)(RT_RING + RT_MAX_BANDS) * RT_N_COUNTERS + 16;
+    if ((e = hipMalloc((void**)&c->d_counters, words * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc");
+    if ((e = hipMemset(c->d_counters, 0, words * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMemset");
+    c->d_sticky = c->d_counters + (size_t)(RT_RING + RT_MAX_BANDS) * RT_N_COUNTERS;
+  }
+  for (int b = 0; b < RT_RING; b++)
+    if ((e = hipEventCreateWithFlags(&c->ev_ring[b], hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
   if ((e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
   for (int b = 0; b < RT_MAX_BANDS; b++)
     if ((e = hipEventCreateWithFlags(&c->ev_band[b], hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
@@ -502,6 +547,8 @@ void rt_context_destroy(RtContext* c) {
   for (void* p : c->d_frame)
     if (p) (void)hipFree(p);
   for (hipEvent_t ev : c->ev_band)
+    if (ev) (void)hipEventDestroy(ev);
+  for (hipEvent_t ev : c->ev_ring)
     if (ev) (void)hipEventDestroy(ev);
   if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -549,15 +596,20 @@ int rt_scene_create(RtContext* ctx, const RtScene* s, RtDeviceScene** out) {
     // a triangle twice gives two entries equal in (t, Shape, u, v), and of such neighbours the reference's
     // Intersections keeps the LATER one (BTreeMap bulk build), whereas ties between different shapes
     // go to the earlier. Duplicates are the same class under the same transformed ancestor; the device copy of a
-    // triangle holds the last of them in the unused `mn` slot.
+    // triangle holds the last of them in the unused `mn` slot.  Duplicates that sit in DIFFERENT groups are merged
+    // too: exact whenever the ray that hits both also passes both groups' box tests, which holds for every mesh
+    // `divide` builds (equal triangles have equal boxes and take the same side at every split); for hand-placed
+    // duplicates in groups with different boxes a ray within rounding of one box's face may report the other id
+    // (the id only: the shapes are equal, so is the colour).
     {
       std::vector<std::pair<uint64_t, uint32_t>> keyed;
       for (uint32_t i = 0; i < s->n_shapes; i++)
         if ((shapes[i].kind_flags & RT_SHAPE_KIND_MASK) >= RT_TRIANGLE) {
           const int32_t par = shapes[i].parent;
           const int64_t anchor = par >= 0 ? (int64_t)s->nodes[par].next_xf + 1 : 0;
-          keyed.emplace_back(((uint64_t)shapes[i].vclass << 32) | (uint64_t)anchor, i);
           memcpy(&shapes[i].mn, &i, sizeof(uint32_t));
+          // a triangle that holds a NaN equals no shape, itself included: it is nobody's duplicate
+          if (shapes[i].vclass != RT_VCLASS_NEVER) keyed.emplace_back(((uint64_t)shapes[i].vclass << 32) | (uint64_t)anchor, i);
         }
       std::sort(keyed.begin(), keyed.end());
       for (size_t a = 0; a < keyed.size();) {
@@ -731,19 +783,36 @@ int rt_render_device(RtContext* ctx, const RtDeviceScene* ds, const RtCamera* ca
   hipStream_t stream = stream_ ? (hipStream_t)stream_ : ctx->stream;
   Scene sc = ds->sc;
   sc.flags = opts ? opts->flags : 0;
+  sc.sticky = ctx->d_sticky;
   RenderParams rp = make_params(opts);
-  HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
-  int rc = launch_part(ctx, sc, cam, rp, part, d_out_rgb, d_aux, stream, ctx->d_counters);
+  unsigned slot = 0;
+  unsigned long long* block = nullptr;
+  int rc = ring_acquire(ctx, stream, &slot, &block);
   if (rc != RT_OK) return rc;
-  HIP_TRY(ctx, hipEventRecord(ctx->ev1, stream));
+  if (stats) HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
+  rc = launch_part(ctx, sc, cam, rp, part, d_out_rgb, d_aux, stream, block);
+  if (rc != RT_OK) return rc;
+  if (stats) HIP_TRY(ctx, hipEventRecord(ctx->ev1, stream));
+  rc = ring_release(ctx, stream, slot);
+  if (rc != RT_OK) return rc;
   if (stats) {
     HIP_TRY(ctx, hipStreamSynchronize(stream));
     double total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    rc = read_stats(ctx, stream, stats, total);
+    rc = read_stats(ctx, stream, stats, total, 1, block);
     if (rc != RT_OK) return rc;
-    if (stats->overflow) return fail(ctx, RT_E_OVERFLOW, "per-ray intersection list overflow");
+    return take_sticky_overflow(ctx, stream);
   }
   return RT_OK;
+}
+
+int rt_check(RtContext* ctx, void* stream_) {
+  if (!ctx) return RT_E_ABI;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (stream_)
+    HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)stream_));
+  else
+    HIP_TRY(ctx, hipDeviceSynchronize());  // every stream of this GPU, the context's own included
+  return take_sticky_overflow(ctx, ctx->stream);
 }
 
 // Host-memory entry point.  The frame buffers live in the context between calls; a full frame is rendered as up to
@@ -787,8 +856,9 @@ int rt_render(RtContext* ctx, const RtDeviceScene* ds, const RtCamera* cam, cons
   }
   Scene sc = ds->sc;
   sc.flags = opts ? opts->flags : 0;
+  sc.sticky = ctx->d_sticky;
   RenderParams rp = make_params(opts);
-  unsigned long long* d_blocks = ctx->d_counters + RT_N_COUNTERS;
+  unsigned long long* d_blocks = ctx->d_counters + (size_t)RT_RING * RT_N_COUNTERS;
   HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   size_t row0 = 0;
   for (int b = 0; b < nb; b++) {
@@ -825,8 +895,7 @@ int rt_render(RtContext* ctx, const RtDeviceScene* ds, const RtCamera* cam, cons
   int rc = read_stats(ctx, ctx->stream, &local, total, nb, d_blocks);
   if (rc != RT_OK) return rc;
   if (stats) *stats = local;
-  if (local.overflow) return fail(ctx, RT_E_OVERFLOW, "per-ray intersection list overflow");
-  return RT_OK;
+  return take_sticky_overflow(ctx, ctx->stream);
 }
 
 int rt_color_at(RtContext* ctx, const RtDeviceScene* ds, const RtRenderOptions* opts, const float* origins,
@@ -862,24 +931,36 @@ int rt_color_at(RtContext* ctx, const RtDeviceScene* ds, const RtRenderOptions* 
   TRY_CLEAN(hipMalloc((void**)&d_id, (size_t)n * sizeof(int32_t)));
   TRY_CLEAN(hipMemcpyAsync(d_o, origins, n3, hipMemcpyHostToDevice, ctx->stream));
   TRY_CLEAN(hipMemcpyAsync(d_d, directions, n3, hipMemcpyHostToDevice, ctx->stream));
-  TRY_CLEAN(hipMemsetAsync(ctx->d_counters, 0, RT_N_COUNTERS * sizeof(unsigned long long), ctx->stream));
+  unsigned slot = 0;
+  unsigned long long* block = nullptr;
+  {
+    int rc_ = ring_acquire(ctx, ctx->stream, &slot, &block);
+    if (rc_ != RT_OK) {
+      cleanup();
+      return rc_;
+    }
+  }
+  TRY_CLEAN(hipMemsetAsync(block, 0, RT_N_COUNTERS * sizeof(unsigned long long), ctx->stream));
   Scene sc = ds->sc;
   sc.flags = opts ? opts->flags : 0;
+  sc.sticky = ctx->d_sticky;
   RenderParams rp = make_params(opts);
   TRY_CLEAN(hipEventRecord(ctx->ev0, ctx->stream));
   RayOut ro{d_o, d_d, n, d_rgb, d_t, d_id, d_uv};
   if (sc.n_nodes == 0) {
     hipLaunchKernelGGL(k_color_at_direct, dim3((n + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, ctx->stream, sc, rp, ro,
-                       remaining, ctx->d_counters);
+                       remaining, block);
   } else {
     const uint32_t blocks = std::min<uint32_t>((n + RT_BLOCK - 1) / RT_BLOCK, ctx->n_cus * RT_BLOCKS_PER_CU);
     const bool cull = (sc.props & RT_SCENE_SHAPE_CULL) != 0;
     auto kern = (sc.flags & RT_RENDER_COUNT_WORK) ? (cull ? k_color_at_jobs<true, true> : k_color_at_jobs<true, false>)
                                                   : (cull ? k_color_at_jobs<false, true> : k_color_at_jobs<false, false>);
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(RT_BLOCK), 0, ctx->stream, sc, rp, ro, remaining, ctx->d_counters);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(RT_BLOCK), 0, ctx->stream, sc, rp, ro, remaining, block);
   }
   TRY_CLEAN(hipGetLastError());
   TRY_CLEAN(hipEventRecord(ctx->ev1, ctx->stream));
+  TRY_CLEAN(hipEventRecord(ctx->ev_ring[slot], ctx->stream));
+  ctx->ring_used[slot] = true;
   TRY_CLEAN(hipStreamSynchronize(ctx->stream));
   if (out_rgb) TRY_CLEAN(hipMemcpy(out_rgb, d_rgb, n3, hipMemcpyDeviceToHost));
   if (hit_t) TRY_CLEAN(hipMemcpy(hit_t, d_t, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
@@ -887,13 +968,12 @@ int rt_color_at(RtContext* ctx, const RtDeviceScene* ds, const RtRenderOptions* 
   if (hit_uv) TRY_CLEAN(hipMemcpy(hit_uv, d_uv, (size_t)n * 2 * sizeof(float), hipMemcpyDeviceToHost));
   RtStats local{};
   double total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-  int rc = read_stats(ctx, ctx->stream, &local, total);
+  int rc = read_stats(ctx, ctx->stream, &local, total, 1, block);
   cleanup();
 #undef TRY_CLEAN
   if (rc != RT_OK) return rc;
   if (stats) *stats = local;
-  if (local.overflow) return fail(ctx, RT_E_OVERFLOW, "per-ray intersection list overflow");
-  return RT_OK;
+  return take_sticky_overflow(ctx, ctx->stream);
 }
 
 }  // extern "C"

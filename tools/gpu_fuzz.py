@@ -182,11 +182,27 @@ def run_seed(seed, n=40000, log=print):
     return bad
 
 
+class _FrameScene:
+    """The world and camera of run_frame(seed), in the form tests/test_gpu_parity.py Raw takes."""
+
+    def __init__(self, seed, cam):
+        self.seed, self.cam = seed, cam
+
+    def build(self, w):
+        mixed_world(w, np.random.RandomState(self.seed), True, bool(self.seed % 2))
+        return w
+
+    def camera(self, hsize, vsize):
+        return self.cam
+
+
 def run_frame(seed, log=print):
     """One mixed world (rich; group-less for odd seeds) rendered whole through Camera::render with a random camera,
-    odd frame sizes, both jitter modes: the bars of tests/test_gpu_parity.py check()."""
-    from raytracer_amd import builder as B
-    from test_gpu_parity import check
+    odd frame sizes, both jitter modes: the bars of tests/test_gpu_parity.py check().  Even seeds have two lights: there
+    the reference re-traces secondary rays per light, so the rays TRACED differ by design and the
+    device's count of the rays the reference casts (RtStats.rays_reference) is held against the oracle's total."""
+    from raytracer_amd import abi, builder as B
+    from test_gpu_parity import Raw, check
     rng = np.random.RandomState(5000 + seed)
     gw, ow = host.new_world(0), oracle.new_world()
     mixed_world(gw, np.random.RandomState(seed), True, bool(seed % 2))
@@ -204,14 +220,16 @@ def run_frame(seed, log=print):
         log(f"frame seed {seed}: skipped, list overflow")
         return 0
     r = ow.render(cam, ro, aux=True)
+    n_lights = int(gw.flatten().n_lights)
     try:
-        check(g, r, f"frame seed {seed}")
+        check(g, r, f"frame seed {seed}", one_light=n_lights == 1)
+        if n_lights != 1:
+            _, _, st = Raw(_FrameScene(seed, cam), (cam.hsize, cam.vsize)).render(flags=abi.RT_RENDER_COUNT_WORK)
+            want = sum(r.stats[k] for k in ("primary", "shadow", "reflect", "refract"))
+            assert st.rays_reference == want, f"rays_reference {st.rays_reference} != oracle total {want}"
     except AssertionError as e:
-        # with several lights the reference traces every secondary ray once per light and the oracle
-        # counts them so; the device traces it once and weights it. check() tests the counts last: all else passed.
-        if not ("ray count" in str(e) and not seed % 2):
-            log(f"frame seed {seed} {cam.hsize}x{cam.vsize}: FAIL {e}")
-            return 1
+        log(f"frame seed {seed} {cam.hsize}x{cam.vsize}: FAIL {e}")
+        return 1
     log(f"frame seed {seed} {cam.hsize}x{cam.vsize}: ok, hits {r.hit_mask.mean():.2f}")
     return 0
 

@@ -19,11 +19,13 @@ def summarise(path: str) -> None:
         "max(workgroup_x) from kernels group by name order by sum(duration) desc").fetchall()
     total = sum(r[2] for r in rows) or 1
     print(f"{'kernel':<60} {'calls':>5} {'total_ms':>10} {'avg_ms':>10} {'min_ms':>10} {'max_ms':>10} {'%':>6} "
-          f"{'vgpr':>5} {'agpr':>5} {'sgpr':>5} {'scratch':>8} {'lds':>6} grid(threads) wg")
+          f"{'avgpr*':>6} {'agpr':>5} {'sgpr':>5} {'scratch':>8} {'lds':>6} grid(threads) wg")
     for r in rows:
         name = r[0] if len(r[0]) <= 60 else r[0][:57] + "..."
         print(f"{name:<60} {r[1]:>5} {r[2] / 1e6:>10.3f} {r[3] / 1e6:>10.3f} {r[4] / 1e6:>10.3f} {r[5] / 1e6:>10.3f} "
-              f"{100.0 * r[2] / total:>6.2f} {r[6]:>5} {r[7]:>5} {r[8]:>5} {r[9]:>8} {r[10]:>6} {r[11]}x{r[12]} {r[13]}")
+              f"{100.0 * r[2] / total:>6.2f} {r[6]:>6} {r[7]:>5} {r[8]:>5} {r[9]:>8} {r[10]:>6} {r[11]}x{r[12]} {r[13]}")
+    print("  (* rocpd's arch_vgpr_count, NOT the allocation: the code object's .vgpr_count / spills are listed by "
+          "tools/kernel_resources.py)")
     pmc = db.execute(
         "select kernel_name, counter_name, count(*), avg(value), min(value), max(value), avg(duration) "
         "from counters_collection group by kernel_name, counter_name order by avg(duration) desc").fetchall()
