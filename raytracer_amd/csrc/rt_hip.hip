@@ -898,55 +898,28 @@ int rt_render(RtContext* ctx, const RtDeviceScene* ds, const RtCamera* cam, cons
   return take_sticky_overflow(ctx, ctx->stream);
 }
 
-int rt_color_at(RtContext* ctx, const RtDeviceScene* ds, const RtRenderOptions* opts, const float* origins,
-                const float* directions, uint32_t n, uint32_t remaining, float* out_rgb, float* hit_t,
-                int32_t* hit_id, float* hit_uv, RtStats* stats) {
-  if (!ctx || !ds || (n && (!origins || !directions))) return RT_E_ABI;
-  if (ds->owner != ctx) return fail(ctx, RT_E_ABI, "scene belongs to another context");
-  if (remaining + 1 > RT_MAX_RAY_STACK) return fail(ctx, RT_E_SCENE, "remaining exceeds the device ray stack");
-  auto t0 = std::chrono::steady_clock::now();
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
-  if (n == 0) return RT_OK;
-  float *d_o = nullptr, *d_d = nullptr, *d_rgb = nullptr, *d_t = nullptr, *d_uv = nullptr;
-  int32_t* d_id = nullptr;
-  auto cleanup = [&]() {
-    for (void* p : {(void*)d_o, (void*)d_d, (void*)d_rgb, (void*)d_t, (void*)d_uv, (void*)d_id})
-      if (p) (void)hipFree(p);
-  };
-#define TRY_CLEAN(expr)                                                                      \
-  do {                                                                                       \
-    hipError_t e_ = (expr);                                                                  \
-    if (e_ != hipSuccess) {                                                                  \
-      cleanup();                                                                             \
-      return fail(ctx, e_ == hipErrorOutOfMemory ? RT_E_OOM : RT_E_DEVICE,                   \
-                  std::string(#expr) + ": " + hipGetErrorString(e_));                        \
-    }                                                                                        \
-  } while (0)
-  size_t n3 = (size_t)n * 3 * sizeof(float);
-  TRY_CLEAN(hipMalloc((void**)&d_o, n3));
-  TRY_CLEAN(hipMalloc((void**)&d_d, n3));
-  TRY_CLEAN(hipMalloc((void**)&d_rgb, n3));
-  TRY_CLEAN(hipMalloc((void**)&d_t, (size_t)n * sizeof(float)));
-  TRY_CLEAN(hipMalloc((void**)&d_uv, (size_t)n * 2 * sizeof(float)));
-  TRY_CLEAN(hipMalloc((void**)&d_id, (size_t)n * sizeof(int32_t)));
-  TRY_CLEAN(hipMemcpyAsync(d_o, origins, n3, hipMemcpyHostToDevice, ctx->stream));
-  TRY_CLEAN(hipMemcpyAsync(d_d, directions, n3, hipMemcpyHostToDevice, ctx->stream));
-  unsigned slot = 0;
-  unsigned long long* block = nullptr;
-  {
-    int rc_ = ring_acquire(ctx, ctx->stream, &slot, &block);
-    if (rc_ != RT_OK) {
-      cleanup();
-      return rc_;
-    }
-  }
-  TRY_CLEAN(hipMemsetAsync(block, 0, RT_N_COUNTERS * sizeof(unsigned long long), ctx->stream));
+namespace {
+// device staging of one rt_color_at batch: rays in, colours and hits out
+struct RayBufs {
+  float *o = nullptr, *d = nullptr, *rgb = nullptr, *t = nullptr, *uv = nullptr;
+  int32_t* id = nullptr;
+};
+// Copies the rays in, launches, copies the results out and reads the counters of `block` (zeroed here).  Allocates
+// nothing: the buffers and the counter block are the caller's.
+int color_at_run(RtContext* ctx, const RtDeviceScene* ds, const RtRenderOptions* opts, const float* origins,
+                 const float* directions, uint32_t n, uint32_t remaining, float* out_rgb, float* hit_t, int32_t* hit_id,
+                 float* hit_uv, RtStats* stats_out, const RayBufs& b, unsigned long long* block,
+                 std::chrono::steady_clock::time_point t0) {
+  const size_t n3 = (size_t)n * 3 * sizeof(float);
+  HIP_TRY(ctx, hipMemcpyAsync(b.o, origins, n3, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(b.d, directions, n3, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(block, 0, RT_N_COUNTERS * sizeof(unsigned long long), ctx->stream));
   Scene sc = ds->sc;
   sc.flags = opts ? opts->flags : 0;
   sc.sticky = ctx->d_sticky;
   RenderParams rp = make_params(opts);
-  TRY_CLEAN(hipEventRecord(ctx->ev0, ctx->stream));
-  RayOut ro{d_o, d_d, n, d_rgb, d_t, d_id, d_uv};
+  HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  RayOut ro{b.o, b.d, n, b.rgb, b.t, b.id, b.uv};
   if (sc.n_nodes == 0) {
     hipLaunchKernelGGL(k_color_at_direct, dim3((n + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, ctx->stream, sc, rp, ro,
                        remaining, block);
@@ -957,23 +930,57 @@ int rt_color_at(RtContext* ctx, const RtDeviceScene* ds, const RtRenderOptions* 
                                                   : (cull ? k_color_at_jobs<false, true> : k_color_at_jobs<false, false>);
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(RT_BLOCK), 0, ctx->stream, sc, rp, ro, remaining, block);
   }
-  TRY_CLEAN(hipGetLastError());
-  TRY_CLEAN(hipEventRecord(ctx->ev1, ctx->stream));
-  TRY_CLEAN(hipEventRecord(ctx->ev_ring[slot], ctx->stream));
-  ctx->ring_used[slot] = true;
-  TRY_CLEAN(hipStreamSynchronize(ctx->stream));
-  if (out_rgb) TRY_CLEAN(hipMemcpy(out_rgb, d_rgb, n3, hipMemcpyDeviceToHost));
-  if (hit_t) TRY_CLEAN(hipMemcpy(hit_t, d_t, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
-  if (hit_id) TRY_CLEAN(hipMemcpy(hit_id, d_id, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
-  if (hit_uv) TRY_CLEAN(hipMemcpy(hit_uv, d_uv, (size_t)n * 2 * sizeof(float), hipMemcpyDeviceToHost));
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  if (out_rgb) HIP_TRY(ctx, hipMemcpyAsync(out_rgb, b.rgb, n3, hipMemcpyDeviceToHost, ctx->stream));
+  if (hit_t) HIP_TRY(ctx, hipMemcpyAsync(hit_t, b.t, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  if (hit_id) HIP_TRY(ctx, hipMemcpyAsync(hit_id, b.id, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  if (hit_uv) HIP_TRY(ctx, hipMemcpyAsync(hit_uv, b.uv, (size_t)n * 2 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   RtStats local{};
   double total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   int rc = read_stats(ctx, ctx->stream, &local, total, 1, block);
-  cleanup();
-#undef TRY_CLEAN
   if (rc != RT_OK) return rc;
-  if (stats) *stats = local;
+  if (stats_out) *stats_out = local;
   return take_sticky_overflow(ctx, ctx->stream);
+}
+}  // namespace
+
+int rt_color_at(RtContext* ctx, const RtDeviceScene* ds, const RtRenderOptions* opts, const float* origins,
+                const float* directions, uint32_t n, uint32_t remaining, float* out_rgb, float* hit_t,
+                int32_t* hit_id, float* hit_uv, RtStats* stats) {
+  if (!ctx || !ds || (n && (!origins || !directions))) return RT_E_ABI;
+  if (ds->owner != ctx) return fail(ctx, RT_E_ABI, "scene belongs to another context");
+  if (remaining + 1 > RT_MAX_RAY_STACK) return fail(ctx, RT_E_SCENE, "remaining exceeds the device ray stack");
+  auto t0 = std::chrono::steady_clock::now();
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (n == 0) return RT_OK;
+  RayBufs b;
+  auto cleanup = [&]() {
+    for (void* p : {(void*)b.o, (void*)b.d, (void*)b.rgb, (void*)b.t, (void*)b.uv, (void*)b.id})
+      if (p) (void)hipFree(p);
+  };
+  const size_t n3 = (size_t)n * 3 * sizeof(float);
+  hipError_t e = hipMalloc((void**)&b.o, n3);
+  if (e == hipSuccess) e = hipMalloc((void**)&b.d, n3);
+  if (e == hipSuccess) e = hipMalloc((void**)&b.rgb, n3);
+  if (e == hipSuccess) e = hipMalloc((void**)&b.t, (size_t)n * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc((void**)&b.uv, (size_t)n * 2 * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc((void**)&b.id, (size_t)n * sizeof(int32_t));
+  if (e != hipSuccess) {
+    cleanup();
+    return fail(ctx, e == hipErrorOutOfMemory ? RT_E_OOM : RT_E_DEVICE, std::string("rt_color_at buffers: ") + hipGetErrorString(e));
+  }
+  unsigned slot = 0;
+  unsigned long long* block = nullptr;
+  int rc = ring_acquire(ctx, ctx->stream, &slot, &block);
+  if (rc == RT_OK) {
+    rc = color_at_run(ctx, ds, opts, origins, directions, n, remaining, out_rgb, hit_t, hit_id, hit_uv, stats, b, block, t0);
+    (void)ring_release(ctx, ctx->stream, slot);
+  }
+  (void)hipStreamSynchronize(ctx->stream);
+  cleanup();
+  return rc;
 }
 
 }  // extern "C"
