@@ -41,7 +41,8 @@ enum {
   RT_E_DEVICE = -2,  /* HIP error */
   RT_E_OOM = -3,     /* device allocation failed */
   RT_E_SCENE = -4,   /* scene violates a device limit (chain depth, csg depth, ...) */
-  RT_E_OVERFLOW = -5 /* a per-ray intersection list overflowed its capacity; image is invalid */
+  RT_E_OVERFLOW = -5, /* a per-ray intersection list overflowed its capacity; image is invalid */
+  RT_E_LIMIT = -6     /* an argument exceeds a fixed capacity of the entry point (rt_color_at_static) */
 };
 
 /* shape kinds — order of the reference enum (src/shapes.rs:27-36) */
@@ -303,6 +304,21 @@ int rt_check(RtContext*, void* stream);
 int rt_color_at(RtContext*, const RtDeviceScene*, const RtRenderOptions*, const float* origins,
                 const float* directions, uint32_t n, uint32_t remaining, float* out_rgb, float* hit_t,
                 int32_t* hit_id, float* hit_uv, RtStats* stats);
+
+/* rt_color_at for callers that cannot allocate device memory.  NO COUNTERPART IN THE REFERENCE: it exists for callers
+ * of this library that must not reach hipMalloc / hipFree -- tight serving loops that shade small ray batches, code
+ * under HIP graph capture on another stream, harnesses that forbid allocation -- where rt_color_at, which allocates
+ * and frees six staging buffers per call, cannot be used.  Same arguments, same results bit for bit; the rays and
+ * results are staged through a fixed array in device memory that the library holds per GPU for the life of the
+ * process (13 * 4 * RT_STATIC_MAX_RAYS bytes + one counter block = 3.3 MB).
+ *   - n > RT_STATIC_MAX_RAYS is rejected with RT_E_LIMIT (split the batch);
+ *   - calls no hipMalloc, hipFree or other allocating routine; synchronous like rt_color_at;
+ *   - every call on a GPU shares that GPU's array, whatever the context: calls that overlap on one GPU race
+ *     (serialise them); the array keeps the last call's contents, which the next call overwrites before reading. */
+#define RT_STATIC_MAX_RAYS 65536u
+int rt_color_at_static(RtContext*, const RtDeviceScene*, const RtRenderOptions*, const float* origins,
+                       const float* directions, uint32_t n, uint32_t remaining, float* out_rgb, float* hit_t,
+                       int32_t* hit_id, float* hit_uv, RtStats* stats);
 
 #ifdef __cplusplus
 }

@@ -6,7 +6,8 @@ import ctypes as C
 import numpy as np
 
 RT_ABI_VERSION = 1
-RT_OK, RT_E_ABI, RT_E_DEVICE, RT_E_OOM, RT_E_SCENE, RT_E_OVERFLOW = 0, -1, -2, -3, -4, -5
+RT_OK, RT_E_ABI, RT_E_DEVICE, RT_E_OOM, RT_E_SCENE, RT_E_OVERFLOW, RT_E_LIMIT = 0, -1, -2, -3, -4, -5, -6
+RT_STATIC_MAX_RAYS = 65536
 RT_SHAPE_KIND_MASK, RT_SHAPE_SHADOW, RT_SHAPE_CLOSED = 0xF, 0x10, 0x20
 RT_VCLASS_NEVER = 0xFFFFFFFF
 RT_NODE_ALL_TRIS, RT_NODE_PRUNABLE = 1, 2
@@ -97,7 +98,7 @@ AUX_TRI = np.dtype([("p1", "<f4", 3), ("shape", "<u4"), ("e1", "<f4", 3), ("owne
 assert AUX_NODE.itemsize == 80 and AUX_TRI.itemsize == 48
 
 EXPORTS = ["rt_accel_build", "rt_accel_free", "rt_abi_version", "rt_context_create", "rt_context_destroy", "rt_last_error", "rt_scene_create",
-           "rt_scene_destroy", "rt_part_rows", "rt_render", "rt_render_device", "rt_check", "rt_color_at"]
+           "rt_scene_destroy", "rt_part_rows", "rt_render", "rt_render_device", "rt_check", "rt_color_at", "rt_color_at_static"]
 
 
 def declare(lib: C.CDLL) -> None:
@@ -121,6 +122,8 @@ def declare(lib: C.CDLL) -> None:
     lib.rt_color_at.restype = C.c_int
     lib.rt_color_at.argtypes = [P, P, C.POINTER(RtRenderOptions), P, P, C.c_uint32, C.c_uint32, P, P, P, P,
                                 C.POINTER(RtStats)]
+    lib.rt_color_at_static.restype = C.c_int
+    lib.rt_color_at_static.argtypes = lib.rt_color_at.argtypes
 
 
 def _view(ptr, count, dtype):

@@ -273,6 +273,18 @@ __global__ __launch_bounds__(RT_BLOCK) void k_color_at_direct(Scene sc, RenderPa
 }  // namespace
 
 // =========================================================================================
+// rt_color_at_static: staging and counters of the allocation-free entry point.  One array per GPU the library runs
+// on, held until the process ends.  In host code the NAME below is only a stand-in for the symbol, not a device
+// address: rt_context_create asks the runtime for this device's address (hipGetSymbolAddress) and everything --
+// kernel arguments, memsets, copies -- uses that pointer.
+//   layout (RT_STATIC_MAX_RAYS = N): origins 3N f32 | directions 3N | colours 3N | hit t N | hit uv 2N | hit id N i32
+//                                    | counter block (RT_N_COUNTERS u64, 256-B aligned)
+// =========================================================================================
+#define RT_STATIC_WORDS (13u * RT_STATIC_MAX_RAYS)
+#define RT_STATIC_BYTES (RT_STATIC_WORDS * 4u + RT_N_COUNTERS * 8u)
+static __device__ __align__(256) unsigned char scratch[RT_STATIC_BYTES];
+
+// =========================================================================================
 // host side of the ABI
 // =========================================================================================
 #define RT_RING 8       // counter blocks of the asynchronous launches
@@ -291,6 +303,7 @@ struct RtContext {
   bool ring_used[RT_RING] = {};
   unsigned ring_next = 0;
   unsigned long long* d_sticky = nullptr;
+  unsigned char* static_scratch = nullptr;  // this device's copy of `scratch` (hipGetSymbolAddress), never the symbol's name
   uint32_t n_cus = 256;
   // frame buffers of rt_render, kept between calls (grow only)
   void* d_frame[4] = {nullptr, nullptr, nullptr, nullptr};  // rgb, mask, object id, hit t
@@ -533,6 +546,9 @@ int rt_context_create(int device, RtContext** out) {
   }
   for (int b = 0; b < RT_RING; b++)
     if ((e = hipEventCreateWithFlags(&c->ev_ring[b], hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
+  // each GPU holds its own copy of the static scratch array at its own address: look it up with this device current
+  if ((e = hipGetSymbolAddress((void**)&c->static_scratch, HIP_SYMBOL(scratch))) != hipSuccess || !c->static_scratch)
+    return bail(e, "hipGetSymbolAddress(scratch)");
   if ((e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
   for (int b = 0; b < RT_MAX_BANDS; b++)
     if ((e = hipEventCreateWithFlags(&c->ev_band[b], hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
@@ -981,6 +997,34 @@ int rt_color_at(RtContext* ctx, const RtDeviceScene* ds, const RtRenderOptions* 
   (void)hipStreamSynchronize(ctx->stream);
   cleanup();
   return rc;
+}
+
+// rt_color_at without any allocation: the rays are staged through this GPU's static scratch array.
+int rt_color_at_static(RtContext* ctx, const RtDeviceScene* ds, const RtRenderOptions* opts, const float* origins,
+                       const float* directions, uint32_t n, uint32_t remaining, float* out_rgb, float* hit_t,
+                       int32_t* hit_id, float* hit_uv, RtStats* stats) {
+  if (!ctx || !ds || (n && (!origins || !directions))) return RT_E_ABI;
+  if (ds->owner != ctx) return fail(ctx, RT_E_ABI, "scene belongs to another context");
+  if (remaining + 1 > RT_MAX_RAY_STACK) return fail(ctx, RT_E_SCENE, "remaining exceeds the device ray stack");
+  if (n > RT_STATIC_MAX_RAYS)
+    return fail(ctx, RT_E_LIMIT, "rt_color_at_static: " + std::to_string(n) + " rays exceed RT_STATIC_MAX_RAYS (" +
+                                     std::to_string(RT_STATIC_MAX_RAYS) + "); split the batch or use rt_color_at");
+  auto t0 = std::chrono::steady_clock::now();
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (n == 0) return RT_OK;
+  float* base = reinterpret_cast<float*>(ctx->static_scratch);
+  const size_t N = RT_STATIC_MAX_RAYS;
+  RayBufs b;
+  b.o = base;
+  b.d = base + 3 * N;
+  b.rgb = base + 6 * N;
+  b.t = base + 9 * N;
+  b.uv = base + 10 * N;
+  b.id = reinterpret_cast<int32_t*>(base + 12 * N);
+  unsigned long long* block = reinterpret_cast<unsigned long long*>(ctx->static_scratch + (size_t)RT_STATIC_WORDS * 4u);
+  // the array keeps the last call's contents: the counter block is zeroed by color_at_run, every output word the
+  // caller reads (entries 0..n) is written by the kernel
+  return color_at_run(ctx, ds, opts, origins, directions, n, remaining, out_rgb, hit_t, hit_id, hit_uv, stats, b, block, t0);
 }
 
 }  // extern "C"
