@@ -52,7 +52,7 @@ constexpr uint32_t kMinTris = 12;    // subtrees with fewer triangles keep the r
 #endif
 static_assert(RT_LEAF_TRIS >= 1 && RT_LEAF_TRIS <= 15, "leaf count is a 4-bit field");
 constexpr uint32_t kLeafTris = RT_LEAF_TRIS;    // max triangles per leaf
-constexpr int kMaxDepth = 22;        // device stack holds kMaxDepth + 2 entries
+constexpr int kMaxDepth = 20;        // device stack holds kMaxDepth + 2 entries (RT_AUX_STACK)
 constexpr float kPadRel = 0.01f;     // static box padding relative to the triangle's largest extent
 constexpr float kPadAbs = 4e-6f;     // ... plus this times the largest |coordinate|
 

@@ -20,7 +20,7 @@
 #ifndef RT_XS_CAP
 #define RT_XS_CAP 96         // per-ray entries for the n1/n2 container walk
 #endif
-#define RT_AUX_STACK 24      // per-lane auxiliary-BVH stack entries, kept in LDS (rt_accel.h kMaxDepth + 2)
+#define RT_AUX_STACK 22      // per-lane auxiliary-BVH stack entries, kept in LDS (rt_accel.h kMaxDepth + 2)
 #ifndef RT_BLOCK
 #define RT_BLOCK 256         // threads per block of every kernel that traces (LDS stack stride): 256 or 64
 #endif
@@ -805,6 +805,230 @@ __device__ inline bool aux_intersect(const Scene& sc, uint32_t root_node, uint32
 }
 
 // ---------------------------------------------------------------------------------------
+// The same traversal run by the WHOLE WAVE (closest / shadow searches; the collect pass keeps aux_intersect).
+// A wave's rays need trees of very different lengths: most finish in a few steps or need no tree at all, a few
+// (grazing rays) take a hundred, and with one ray per lane the wave issues every instruction of the long ones for
+// 64 lanes (measured: 30 % of the lanes active in node steps).  Here every lane of the wave takes part in the loop,
+// and lanes without work of their own STEAL: a busy lane hands the deferred subtree at the BOTTOM of its stack (the
+// largest, farthest one) to an idle lane, which traverses it for the owner's ray.  Candidates from all helpers meet
+// in one 64-bit word per owner in LDS, (t bits << 32 | shape): for t > 0 its unsigned order is the reference's
+// (t, insertion rank) order, so ds_min_u64 is Intersections::hit(), and every helper prunes against
+// the owner's current best.  Stolen subtrees are farther than what the victim keeps, so part of that work is
+// speculative -- it runs on lanes that would otherwise idle through the same instructions.
+// Results are independent of who traverses what: the set of accepted candidates is the same, min is commutative.
+// The winner's (u, v) are not carried: the shading step recomputes them for smooth triangles (same arithmetic).
+// ---------------------------------------------------------------------------------------
+#ifndef RT_STEAL_MIN_IDLE
+#define RT_STEAL_MIN_IDLE 24  // lanes without work before the wave looks for work to hand out
+#endif
+#ifndef RT_STEAL_PERIOD
+#define RT_STEAL_PERIOD 2     // ... every this many steps
+#endif
+#ifndef RT_STEAL_MAX_PAIRS
+#define RT_STEAL_MAX_PAIRS 16
+#endif
+#ifndef RT_LEAF_BATCH
+#define RT_LEAF_BATCH 24      // lanes waiting at a leaf that start a leaf step while others could still descend
+#endif
+__device__ __forceinline__ unsigned long long* aux_keys() {
+  __shared__ unsigned long long keys[RT_BLOCK];
+  return keys;
+}
+__device__ __forceinline__ unsigned long long hit_key(float t, int shape) {
+  return ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)(uint32_t)shape;
+}
+__device__ __forceinline__ float pull_f(int lane, float v) {
+  return __int_as_float(__builtin_amdgcn_ds_bpermute(lane << 2, __float_as_int(v)));
+}
+__device__ __forceinline__ uint32_t pull_u(int lane, uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_ds_bpermute(lane << 2, (int)v);
+}
+// want: this lane's ray reached the subtree root (wave-uniform root_node / aux_root).  handled (for lanes that want):
+// false = this ray must take the reference walk through the subtree.  Every lane of the wave must call.
+template <bool COUNT>
+__device__ inline void aux_coop(const Scene& sc, const uint32_t root_node, const uint32_t aux_root, const Ray& cur, Sink& sink,
+                                Counters& cn, const bool want, bool& handled) {
+  const f4n RT_CONST_AS* A = cst(reinterpret_cast<const f4n*>(sc.aux_nodes)) + 5u * (size_t)aux_root;
+  const f4n h0 = A[0], h1 = A[1];
+  // ---- the task of this lane's own ray (see aux_intersect for the bounds behind the numbers) ----
+  Ray T = cur;
+  float Tkmax, Tpadk;
+  bool work;
+  {
+    const bool axis_ok = __builtin_fabsf(cur.d.x) >= 1e-4f || __builtin_fabsf(cur.d.y) >= 1e-4f || __builtin_fabsf(cur.d.z) >= 1e-4f;
+    const V3 oc = cur.o - v3(h0.x, h0.y, h0.z);
+    const float S = magnitude(oc) + h0.w;
+    Tkmax = 1e4f * h1.y * magnitude(cur.d);
+    Tpadk = 1.43e-6f * (S + h1.x);
+    work = want && axis_ok && (Tpadk * Tkmax < __builtin_inff());
+  }
+  handled = work;
+  float Tbound = sink.bound;
+  int Tmode = sink.mode;
+  uint32_t Towner = threadIdx.x;
+  const uint32_t shape_base = __float_as_uint(h1.w);
+  unsigned long long* keys = aux_keys();
+  const unsigned long long key0 = hit_key(sink.t, sink.shape);
+  if (work) __hip_atomic_store(&keys[Towner], key0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  // values derived from the task's ray; recomputed after a steal
+  float dm, inv_dm, lo0;
+  V3 dn, inv;
+  bool use_cone;
+  auto derive = [&]() {
+    dm = magnitude(T.d);
+    dn = T.d / dm;
+    inv_dm = __builtin_amdgcn_rcpf(dm) * 1.000001f;
+    use_cone = Tpadk * Tkmax > RT_CONE_MIN_PAD * h1.x;
+    inv = v3(__builtin_amdgcn_rcpf(T.d.x), __builtin_amdgcn_rcpf(T.d.y), __builtin_amdgcn_rcpf(T.d.z));
+    lo0 = 0.f;  // closest / shadow searches never want t <= 0
+  };
+  derive();
+  uint32_t* stk = aux_stack();
+  int sp = 0, bot = 0;  // deferred subtrees of this lane: rows [bot, sp) of its column
+  uint32_t ref = __float_as_uint(h1.z) << 4;
+  uint32_t iter = 0;
+  const uint32_t lane = threadIdx.x & 63u;
+  while (true) {
+    // One kind of step per iteration.  Lanes that have reached a leaf wait while others still descend, until enough of
+    // them are there: a leaf step is a serial loop over up to RT_LEAF_TRIS triangles, and run for a few lanes at a time
+    // (every iteration, as lanes happen to arrive) it dominated the cost (16 % of the lanes active in it).
+    const bool at_leaf = work && (ref & 15u) != 0u;
+    const unsigned long long leaf_lanes = __builtin_amdgcn_ballot_w64(at_leaf);
+    const bool leaf_phase = (uint32_t)__builtin_popcountll(leaf_lanes) >= RT_LEAF_BATCH ||
+                            leaf_lanes == __builtin_amdgcn_ballot_w64(work);
+    if (work && at_leaf == leaf_phase) {
+      const unsigned long long kcur = __hip_atomic_load(&keys[Towner], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      // nothing at or beyond lim can matter: the owner's best so far, capped by its bound (shadow: the light);
+      // key 0 = a shadow search that has its occluder
+      const float lim = kcur == 0ull ? -__builtin_inff() : __builtin_fminf(__uint_as_float((uint32_t)(kcur >> 32)), Tbound);
+      uint32_t next = RT_AUX_NONE;
+      const uint32_t cnt = ref & 15u, idx = ref >> 4;
+      if (kcur == 0ull) {
+        sp = bot;  // drop what is left
+      } else if (cnt == 0u) {
+        const f4n RT_CONST_AS* N = cst(reinterpret_cast<const f4n*>(sc.aux_nodes)) + 5u * (size_t)idx;
+        f4n n0 = N[0], n1 = N[1], n2 = N[2], n3 = N[3];
+        RT_UTIL(0);
+        if (COUNT) cn.aux_tests += 2;
+        float kb = Tkmax;
+        f4n n4 = f4n{0.f, 0.f, 0.f, -2.f};
+        if (use_cone) n4 = N[4];
+        if (n4.w >= -1.f) {  // normal cone, see aux_intersect
+          float ik2 = n4.x * n4.x + n4.y * n4.y + n4.z * n4.z;
+          float cp = __builtin_fabsf(dn.x * n4.x + dn.y * n4.y + dn.z * n4.z);
+          float sw = __builtin_amdgcn_sqrtf(__builtin_fmaxf(0.f, 1.f - n4.w * n4.w));
+          float q = cp * n4.w - __builtin_amdgcn_sqrtf(__builtin_fmaxf(0.f, ik2 - cp * cp)) * sw;
+          if (q > 0.f && q * q > 1e-4f * ik2) kb = __builtin_fminf(Tkmax, __builtin_amdgcn_rcpf(q) * 1.06f);
+        }
+        const float pad = Tpadk * kb;
+        const float tpad = pad * inv_dm;
+        const float lo = lo0 - tpad;
+        const float hi = (lim + 1e-5f * __builtin_fabsf(lim)) + tpad;
+        float tl, tr;
+        const bool hl = aux_box(T.o, inv, pad, n0, n1, lo, hi, tl);
+        const bool hr = aux_box(T.o, inv, pad, n2, n3, lo, hi, tr);
+        const uint32_t rl = (__float_as_uint(n0.w) << 4) | __float_as_uint(n1.w);
+        const uint32_t rr = (__float_as_uint(n2.w) << 4) | __float_as_uint(n3.w);
+        if (hl && hr) {
+          const bool left_first = !(tr < tl);
+          next = left_first ? rl : rr;
+          if (sp < RT_AUX_STACK) stk[(sp++) * RT_BLOCK] = left_first ? rr : rl;
+          else cn.overflow++;
+        } else if (hl || hr) {
+          next = hl ? rl : rr;
+        }
+      } else {
+        if (COUNT) cn.tri_tests += cnt;
+        RT_UTIL(1);
+        const f4n RT_CONST_AS* Tr = cst(reinterpret_cast<const f4n*>(sc.aux_tris)) + 3u * (size_t)idx;
+        for (uint32_t k = 0; k < cnt; k++) {
+          f4n a = Tr[3 * k], b = Tr[3 * k + 1], c = Tr[3 * k + 2];
+          const uint32_t kf = __float_as_uint(c.w);
+          const bool takes = (kf & RT_SHAPE_SHADOW) ? Tmode != SINK_CLOSEST_NOSHADOW : Tmode != SINK_ANY_SHADOW;
+          float t, u, v;
+          if (takes && isect_triangle(T, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), v3(c.x, c.y, c.z), t, u, v)) {
+            const uint32_t shape = shape_base + __float_as_uint(a.w);
+            const unsigned long long kc = hit_key(t, (int)shape);
+            const unsigned long long kn = __hip_atomic_load(&keys[Towner], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            // Sink::wants: positive, in front of the bound, before the best so far in (t, rank) order
+            if (t > 0.f && !(t >= Tbound) && kc < kn && aux_gate<COUNT>(sc, root_node + __float_as_uint(b.w), root_node, T, cn))
+              __hip_atomic_fetch_min(&keys[Towner], Tmode == SINK_ANY_SHADOW ? 0ull : kc, __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        }
+      }
+      if (next == RT_AUX_NONE) {
+        if (sp > bot)
+          next = stk[(--sp) * RT_BLOCK];
+        else
+          work = false;
+      }
+      ref = next;
+    }
+    const unsigned long long busy = __builtin_amdgcn_ballot_w64(work);
+    if (busy == 0ull) break;
+    // ---- hand deferred subtrees to lanes without work ----
+    iter++;
+    const uint32_t n_idle = 64u - (uint32_t)__builtin_popcountll(busy);
+    if (n_idle >= RT_STEAL_MIN_IDLE && (iter % RT_STEAL_PERIOD) == 0u) {
+      unsigned long long donors = __builtin_amdgcn_ballot_w64(work && sp > bot);
+      if (donors != 0ull) {
+        unsigned long long idle = ~busy;
+        int victim = -1;     // thief: the lane it takes from
+        bool gives = false;  // donor: its bottom entry goes to a thief
+        for (int pair = 0; pair < RT_STEAL_MAX_PAIRS && donors != 0ull && idle != 0ull; pair++) {
+          const uint32_t d = (uint32_t)__builtin_ctzll(donors), th = (uint32_t)__builtin_ctzll(idle);
+          donors &= donors - 1ull;
+          idle &= idle - 1ull;
+          if (lane == th) victim = (int)d;
+          if (lane == d) gives = true;
+        }
+        uint32_t entry = 0u;
+        if (gives) {
+          entry = stk[bot * RT_BLOCK];
+          bot++;
+        }
+        // thieves pull the task from their victim's registers (every lane executes the pulls; a lane without a victim
+        // reads its own)
+        const int src = victim >= 0 ? victim : (int)lane;
+        const uint32_t e = pull_u(src, entry);
+        const float ox = pull_f(src, T.o.x), oy = pull_f(src, T.o.y), oz = pull_f(src, T.o.z);
+        const float dx = pull_f(src, T.d.x), dy = pull_f(src, T.d.y), dz = pull_f(src, T.d.z);
+        const float km = pull_f(src, Tkmax), pk = pull_f(src, Tpadk), bd = pull_f(src, Tbound);
+        const uint32_t ow = pull_u(src, Towner), md = pull_u(src, (uint32_t)Tmode);
+        if (victim >= 0) {
+          T = Ray{v3(ox, oy, oz), v3(dx, dy, dz)};
+          Tkmax = km;
+          Tpadk = pk;
+          Tbound = bd;
+          Towner = ow;
+          Tmode = (int)md;
+          derive();
+          ref = e;
+          sp = bot = 0;
+          work = true;
+        }
+      }
+    }
+  }
+  // ---- the owner takes its result ----
+  if (handled) {
+    const unsigned long long k = __hip_atomic_load(&keys[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (sink.mode == SINK_ANY_SHADOW) {
+      if (k == 0ull) {
+        sink.lim = -__builtin_inff();
+        sink.bound = -__builtin_inff();
+      }
+    } else if (k != key0) {
+      sink.t = __uint_as_float((uint32_t)(k >> 32));
+      sink.shape = (int)(uint32_t)k;
+      sink.a = sink.b = __builtin_nanf("");  // (u, v): recomputed by the shading step
+      sink.lim = __builtin_fminf(sink.t, sink.bound);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // World::intersect (world.rs:44-62) as one traversal feeding a sink.
 // Groups: stackless depth-first walk over the DFS-ordered node array (skip pointers); the ray is
 // re-expressed in a group's space when the group has a non-identity transform (groups.rs:127-133).
@@ -900,11 +1124,20 @@ __device__ RT_WI_INLINE void world_intersect(const Scene& sc, const Ray& ray, Si
           if (tmin > lim + (1e-4f * __builtin_fabsf(lim) + 1e-4f)) descend = false;
           if (!sink.wants_negative() && tmax < -(1e-4f * __builtin_fabsf(tmax) + 1e-4f)) descend = false;
         }
-        // device copy of a node: the slot of n_children holds the auxiliary BVH of the subtree (RT_NODE_AUX)
+      }
+      // device copy of a node: the slot of n_children holds the auxiliary BVH of the subtree (RT_NODE_AUX)
+      if ((flags & RT_NODE_AUX) && !(sc.flags & RT_RENDER_NO_ACCEL)) {  // wave-uniform
         RT_T0(ta);
-        if (descend && (flags & RT_NODE_AUX) && !(sc.flags & RT_RENDER_NO_ACCEL) &&
-            aux_intersect<COUNT>(sc, i, w3.w, cur, sink, cn))
-          descend = false;
+        bool want = descend;
+        if (want && sink.mode == SINK_COLLECT) {  // the n1/n2 pass keeps a per-lane list: its own traversal
+          if (aux_intersect<COUNT>(sc, i, w3.w, cur, sink, cn)) descend = false;
+          want = false;
+        }
+        if (wave_any(want)) {  // closest / shadow searches: the whole wave traverses, idle lanes help (aux_coop)
+          bool handled = false;
+          aux_coop<COUNT>(sc, i, w3.w, cur, sink, cn, want, handled);
+          if (handled) descend = false;
+        }
         RT_TACC(t_aux, ta);
       }
       if (wave_any(descend)) {
@@ -1422,15 +1655,13 @@ __device__ inline void integrate(const Scene& sc, const RenderParams& rp, const 
       // idle lane: nothing was traced for it
     } else if (job == JOB_SHADE) {
       Hit hit = Hit{sink.t, sink.u(), sink.v(), sink.shape};
-      if (first) {
-        Hit out = hit;
-        out.shape = reported_shape(sc, hit.shape);
-        src.first_hit(item, out);  // outputs of the primary hit go out now instead of riding along in registers
-        first = false;
-      }
       hit_t = hit.t;
       hit_shape = hit.shape;
       if (hit.shape < 0) {
+        if (first) {
+          src.first_hit(item, hit);
+          first = false;
+        }
         st = ST_NEXT_RAY;
       } else {
         if (COUNT) cn.shaded++;
@@ -1443,13 +1674,22 @@ __device__ inline void integrate(const Scene& sc, const RenderParams& rp, const 
         int parent = (int)w0.w;
         float smn = __uint_as_float(w1.z), smx = __uint_as_float(w1.w);
         if ((kf & RT_SHAPE_KIND_MASK) == RT_SMOOTH_TRIANGLE && hit.u != hit.u) {
-          // hit came through a csg list, which does not carry (u,v): recompute them (same arithmetic)
-          Ray local = sray;
+          // the hit came through a csg list or through the wave-wide tree traversal (aux_coop), which do not carry
+          // (u, v): recompute them with the ray in the triangle's space, through the same chain of transforms the
+          // walk applied (same matrices in the same order => same bits)
+          Ray local = parent >= 0 ? ray_in_space_of(sc, cst(sc.nodes)[parent].next_xf, sray) : sray;
           V3 p1, e1, e2;
           load_tri(sc, prim, p1, e1, e2);
-          if (sxf) local = xf_ray(sc, sxf, sray);
+          if (sxf) local = xf_ray(sc, sxf, local);
           float tt;
           isect_triangle(local, p1, e1, e2, tt, hit.u, hit.v);
+        }
+        if (first) {
+          // outputs of the primary hit go out now instead of riding along in registers; (u, v) exist for smooth
+          // triangles only (intersections.rs:34-41)
+          const bool smooth = (kf & RT_SHAPE_KIND_MASK) == RT_SMOOTH_TRIANGLE;
+          src.first_hit(item, Hit{hit.t, smooth ? hit.u : 0.f, smooth ? hit.v : 0.f, reported_shape(sc, hit.shape)});
+          first = false;
         }
         V3 point = sray.o + hit.t * sray.d;
         V3 eyev = -sray.d;
