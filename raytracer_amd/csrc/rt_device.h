@@ -1532,9 +1532,7 @@ __device__ __forceinline__ void pk_st3(const Park& pk, int k, V3 x) {
 // of the item's random numbers), first_hit(item, hit) and finish(item, colour, work).  `queue` is a zeroed counter in device memory.
 // Every wave leaves the loop: each refill advances the queue, and a wave whose lanes are all idle either refills
 // or, once the queue has run past total(), breaks.
-#ifndef RT_REFILL_MIN
-#define RT_REFILL_MIN 64
-#endif
+#define RT_QUEUE_STRIDE 8  // u64 slots between the queues of two classes (64 B: one atomic unit each)
 enum { ST_IDLE = 100 };
 template <bool COUNT, bool CULL, class Source>
 __device__ inline void integrate(const Scene& sc, const RenderParams& rp, const Source& src, uint32_t remaining0,
@@ -1545,9 +1543,11 @@ __device__ inline void integrate(const Scene& sc, const RenderParams& rp, const 
   int sp = 0;
   bool first = true;
   const float nl = (float)sc.n_lights;
-  const uint32_t n_items = src.total();
-  bool exhausted = false;  // wave-uniform: the queue has run past the last item
-  unsigned long long chunk_next = 0, chunk_end = 0;  // wave-uniform: tiles already drawn from the queue, not yet started
+  bool exhausted = false;  // wave-uniform: every queue has run past its last item
+  unsigned long long chunk_next = 0, chunk_end = 0;  // wave-uniform: items already drawn from the queue, not yet started
+  // HW_REG_XCC_ID (id 20, 4 bits): the XCD this wave runs on
+  uint32_t q_class = Source::kClasses > 1u ? ((uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u) % Source::kClasses : 0u;
+  uint32_t q_tried = 0;
   uint32_t item = 0, work_start = 0;
 
   // the hit being shaded: with the parked ray, enough to rebuild what Computations::prepare holds
@@ -1568,38 +1568,46 @@ __device__ inline void integrate(const Scene& sc, const RenderParams& rp, const 
   int job = JOB_SHADE;
   int st = ST_IDLE;
   while (true) {
-    // ---------------- refill idle lanes from the queue ----------------
+    // ---------------- refill: a wave whose lanes are all idle takes the next tile(s) ----------------
+    // The work is split into Source::kClasses classes, one queue each.  A wave draws from the class of the XCD it runs
+    // on (every XCD has its own L2: a class is a fixed set of screen regions, so an XCD keeps meeting the same part of
+    // the scene's trees) and moves on to the other classes' queues when its own is empty, so the split costs no balance.
     {
-      const unsigned long long idle = __builtin_amdgcn_ballot_w64(st == ST_IDLE);
-      const uint32_t n_idle = (uint32_t)__builtin_popcountll(idle);
-      if (!exhausted && (n_idle >= RT_REFILL_MIN || n_idle == (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(true)))) {
-        unsigned long long base = 0;
+      if (!exhausted && !wave_any(st != ST_IDLE)) {
         const uint32_t lane = threadIdx.x & 63u;
-        // A whole-wave refill draws rp.queue_chunk tiles with one atomic and works through them: all waves of the
-        // device add to one address, and at one atomic per tile that alone took 1.7 ms of a 4K frame (130 k tiles),
-        // the whole frame time of the simple scenes. Scenes with heavy tiles keep a chunk of 1 (launch_part): there
-        // a run of neighbouring tiles in one wave cost more than the atomics (dragons 4K 3.5 -> 4.5 ms).
-        if (n_idle == 64u && chunk_next < chunk_end) {
+        unsigned long long base = 0;
+        // A draw takes rp.queue_chunk tiles with one atomic and the wave works through them: at one atomic per tile the
+        // queue alone took 1.7 ms of a 4K frame (130 k tiles), the whole frame time of the simple scenes. Scenes with
+        // heavy tiles keep a chunk of 1 (launch_part): there a run of neighbouring tiles in one wave cost more than
+        // the atomics (dragons 4K 3.5 -> 4.5 ms).
+        if (chunk_next < chunk_end) {
           base = chunk_next;
           chunk_next += 64u;
         } else {
-          const unsigned long long tiles = rp.queue_chunk;
-          const unsigned long long take = n_idle == 64u ? 64ull * tiles : (unsigned long long)n_idle;
-          if (lane == (uint32_t)__builtin_ctzll(idle)) base = atomicAdd(queue, take);
-          base = ((unsigned long long)__builtin_amdgcn_readlane((int)(base >> 32), __builtin_ctzll(idle)) << 32) |
-                 (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)base, __builtin_ctzll(idle));
-          if (n_idle == 64u) {
-            chunk_next = base + 64u;
-            chunk_end = base + take;
+          const unsigned long long take = 64ull * rp.queue_chunk;
+          while (true) {  // wave-uniform
+            const unsigned long long size = src.class_items(q_class);
+            if (lane == 0u) base = atomicAdd(queue + RT_QUEUE_STRIDE * q_class, take);
+            base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) |
+                   (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
+            if (base < size) {
+              chunk_next = base + 64u;
+              chunk_end = base + take < size ? base + take : size;
+              break;
+            }
+            q_class = q_class + 1u == Source::kClasses ? 0u : q_class + 1u;  // this class is done: help with the next
+            if (++q_tried == Source::kClasses) {
+              exhausted = true;
+              break;
+            }
           }
         }
-        if (base + n_idle >= n_items && (n_idle == 64u || chunk_next >= chunk_end)) exhausted = true;
-        if (st == ST_IDLE) {
-          const uint32_t rank = (uint32_t)__builtin_popcountll(idle & ((1ull << lane) - 1ull));
-          const unsigned long long want = base + rank;
+        if (!exhausted) {
+          const unsigned long long want = base + lane;
           Ray primary;
-          if (want < n_items && src.start((uint32_t)want, primary)) {
-            item = (uint32_t)want;
+          uint32_t it = 0;
+          if (want < src.class_items(q_class) && src.start(q_class, (uint32_t)want, it, primary)) {
+            item = it;
             cn.primary++;
             if (COUNT) cn.ref_rays++;
             pk_st3(pk, PK_RESULT, v3(0.f, 0.f, 0.f));
@@ -1619,7 +1627,7 @@ __device__ inline void integrate(const Scene& sc, const RenderParams& rp, const 
       }
       if (!wave_any(st != ST_IDLE)) {
         if (exhausted) break;
-        continue;  // a refill that only drew items outside the image: draw again
+        continue;  // a draw that only held items outside the image: draw again
       }
     }
     const bool active = st != ST_IDLE;

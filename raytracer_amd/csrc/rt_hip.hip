@@ -19,7 +19,7 @@ using namespace rtd;
 
 namespace {
 
-#define RT_N_COUNTERS 32  // u64 slots per counter block: 0-10 RtStats, 11-14 and 16-23 diagnostics, 15 work queue, 24 reference rays
+#define RT_N_COUNTERS 128  // u64 slots per counter block: 0-10 RtStats, 11-14 and 16-23 diagnostics, 24 reference rays, 64.. work queues
 #ifndef RT_BLOCKS_PER_CU
 #define RT_BLOCKS_PER_CU 4  // 256-thread blocks resident per CU at four waves per SIMD
 #endif
@@ -82,7 +82,7 @@ __device__ __forceinline__ void flush_counters(const Counters& cn, unsigned long
 #ifndef RT_CULL_MIN_SHAPES
 #define RT_CULL_MIN_SHAPES 6u
 #endif
-#define RT_QUEUE_SLOT 15  // d_counters slot used as the work queue of the persistent kernels
+#define RT_QUEUE_SLOT 64  // d_counters slot of the first work queue of the persistent kernels (one per class, RT_QUEUE_STRIDE apart)
 
 __device__ __forceinline__ Ray ray_for_pixel(const RtCamera& cam, uint32_t px, uint32_t py) {  // camera.rs:45-64
   float xoffset = ((float)px + 0.5f) * cam.pixel_size;
@@ -113,28 +113,42 @@ __device__ __forceinline__ void write_colour(const Scene& sc, const PixelOut& o,
   if (COUNT && o.ht && (sc.flags & RT_RENDER_WORK_MAP))  // diagnostics: this pixel's traversal work instead of hit t
     o.ht[idx] = (sc.flags & 0x10u) ? work_shadow : (sc.flags & 0x20u) ? work_collect : work;
 }
-// work items of a frame: pixel `item & 63` of 8x8 tile `item >> 6`, tiles in row-major order
+// Work items of a frame: item = (supertile * 256 + tile in supertile) * 64 + pixel in tile.  A tile is 8x8 pixels (one
+// wave), a supertile 16x16 tiles (128x128 pixels); supertile L belongs to class L % 8.  Items past the image edge (ragged
+// tiles and supertiles) are handed out and skipped.
+#define RT_SUPER 16u
 template <bool COUNT>
 struct PixelSource {
+  static constexpr uint32_t kClasses = 8u;
   const Scene* sc;
   RtCamera cam;
   PartInfo part;
   PixelOut o;
-  uint32_t tiles_x, tiles_y;
-  __device__ uint32_t total() const { return tiles_x * tiles_y * 64u; }
-  // Tiles are handed out from the bottom of the image upwards. The frame ends when the last tile drawn is done, so
+  uint32_t super_x, super_y;
+  __device__ unsigned long long class_items(uint32_t c) const {
+    const uint32_t ns = super_x * super_y;
+    return (unsigned long long)(ns > c ? (ns - c + kClasses - 1u) / kClasses : 0u) * (RT_SUPER * RT_SUPER * 64u);
+  }
+  // Supertiles are handed out from the bottom of the image upwards. The frame ends when the last tile drawn is done, so
   // the last tiles should be cheap ones; with a camera above a floor looking slightly down (every sample scene of
   // the reference) the cheap tiles, sky, are at the top. Measured against top-down at 4K: dragons 3.55 -> 3.42 ms,
   // cover 3.58 -> 3.25 ms, dragons 1080p 1.60 -> 1.38 ms; a scene the other way round loses what these gain.
+  __device__ uint32_t item_of(uint32_t c, uint32_t n) const {
+    const uint32_t per = RT_SUPER * RT_SUPER * 64u;
+    return ((n / per) * kClasses + c) * per + n % per;
+  }
   __device__ void locate(uint32_t item, uint32_t& px, uint32_t& ly) const {
-    uint32_t tile = tiles_x * tiles_y - 1u - (item >> 6), w = item & 63u;
-    px = (tile % tiles_x) * 8u + (w & 7u);
-    ly = (tile / tiles_x) * 8u + (w >> 3);
+    const uint32_t w = item & 63u, tis = (item >> 6) & (RT_SUPER * RT_SUPER - 1u);
+    const uint32_t L = super_x * super_y - 1u - (item >> 14);  // 14 = log2(16 * 16 * 64)
+    const uint32_t tx = (L % super_x) * RT_SUPER + (tis & (RT_SUPER - 1u)), ty = (L / super_x) * RT_SUPER + (RT_SUPER - 1u - tis / RT_SUPER);
+    px = tx * 8u + (w & 7u);
+    ly = ty * 8u + (w >> 3);
   }
   __device__ uint32_t global_row(uint32_t ly) const {
     return (ly / part.tile_h) * (part.n_parts * part.tile_h) + part.part * part.tile_h + (ly % part.tile_h);
   }
-  __device__ bool start(uint32_t item, Ray& r) const {
+  __device__ bool start(uint32_t c, uint32_t n, uint32_t& item, Ray& r) const {
+    item = item_of(c, n);
     uint32_t px, ly;
     locate(item, px, ly);
     if (px >= cam.hsize || ly >= part.rows) return false;
@@ -169,7 +183,7 @@ void k_render_jobs(Scene sc, RtCamera cam, RenderParams rp, PartInfo part, Pixel
 #ifdef RT_PHASE_TIMERS
   const uint64_t t_pixel0 = __builtin_readcyclecounter();
 #endif
-  PixelSource<COUNT> src{&sc, cam, part, o, (cam.hsize + 7u) / 8u, (part.rows + 7u) / 8u};
+  PixelSource<COUNT> src{&sc, cam, part, o, (cam.hsize + 8u * RT_SUPER - 1u) / (8u * RT_SUPER), (part.rows + 8u * RT_SUPER - 1u) / (8u * RT_SUPER)};
   Counters cn = {};
   integrate<COUNT, CULL>(sc, rp, src, sc.recursion_limit, counters + RT_QUEUE_SLOT, cn);
 #ifdef RT_PHASE_TIMERS
@@ -234,9 +248,11 @@ __device__ __forceinline__ void write_ray_hit(const RayOut& o, uint32_t i, const
   }
 }
 struct RaySource {
+  static constexpr uint32_t kClasses = 1u;
   RayOut o;
-  __device__ uint32_t total() const { return o.n; }
-  __device__ bool start(uint32_t i, Ray& r) const {
+  __device__ unsigned long long class_items(uint32_t) const { return o.n; }
+  __device__ bool start(uint32_t, uint32_t i, uint32_t& item, Ray& r) const {
+    item = i;
     r = Ray{v3(o.origins[3 * i], o.origins[3 * i + 1], o.origins[3 * i + 2]),
             v3(o.directions[3 * i], o.directions[3 * i + 1], o.directions[3 * i + 2])};
     return true;
@@ -769,7 +785,9 @@ static int launch_part(RtContext* ctx, const Scene& sc, const RtCamera* cam, con
   } else {
     // persistent waves: enough blocks to fill the device at four waves per SIMD, never more than the work
     const uint64_t items = (uint64_t)((cam->hsize + 7u) / 8u) * ((part.rows + 7u) / 8u) * 64u;
-    if (items >= 0xFFFFFFFFull) return fail(ctx, RT_E_ABI, "image too large");
+    // item ids run over whole 128x128 supertiles (PixelSource) and must fit 32 bits
+    const uint64_t super_items = (uint64_t)((cam->hsize + 127u) / 128u) * ((part.rows + 127u) / 128u) * 16384u;
+    if (super_items >= 0xFFFFFFFFull) return fail(ctx, RT_E_ABI, "image too large");
     const uint32_t blocks = (uint32_t)std::min<uint64_t>((items + RT_BLOCK - 1) / RT_BLOCK, (uint64_t)ctx->n_cus * RT_BLOCKS_PER_CU);
     const bool cull = (sc.props & RT_SCENE_SHAPE_CULL) != 0;  // the scene has cull records (rt_scene_create)
     auto kern = count ? (cull ? k_render_jobs<true, true> : k_render_jobs<true, false>)
