@@ -1546,7 +1546,10 @@ __device__ inline void integrate(const Scene& sc, const RenderParams& rp, const 
   bool exhausted = false;  // wave-uniform: every queue has run past its last item
   unsigned long long chunk_next = 0, chunk_end = 0;  // wave-uniform: items already drawn from the queue, not yet started
   // HW_REG_XCC_ID (id 20, 4 bits): the XCD this wave runs on
-  uint32_t q_class = Source::kClasses > 1u ? ((uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u) % Source::kClasses : 0u;
+  // (with more than 8 classes: the XCD picks the class modulo 8, the block the rest)
+  uint32_t q_class = Source::kClasses > 1u
+                         ? (((uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u) + 8u * ((blockIdx.x >> 3) % ((Source::kClasses + 7u) / 8u))) % Source::kClasses
+                         : 0u;
   uint32_t q_tried = 0;
   uint32_t item = 0, work_start = 0;
 
