@@ -603,5 +603,319 @@ inline bool shape_cull_record(const RtScene* s, const RtShape& sh, float out[12]
   return true;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Cull records for whole subtrees under a transformed group.  The reference enters every group by transforming the
+// ray into its space and testing its box (groups.rs:127-133, :110-113), for every ray and every top-level group.  A
+// transformed group gets a record, in the space its PARENT's ray lives in, such that a ray the record rejects cannot be
+// accepted by the f32 test of ANY shape below the group; such a ray skips the subtree without the transform and the
+// box test.  Whatever the reference's own (possibly too small or shifted) box says is then irrelevant: it
+// decides which shapes are reached, and none of them would have produced an intersection.
+// Same record layout and device test as shape_cull_record, plus two coefficients:
+//   reject  <=>  |(c - o) x d| > ( |d| (R + q1 l + kq l^2 + |d| (kd1 l + kd0)) + k1 l + k0 ) (1 + 1e-4),   l = |o - c|
+//   12 floats: {c.xyz, R} {q1, 0, kq, k1} {k0, kd1, kd0, 0}
+// Per shape below the group, with M = the chain of inverse transforms from the record's space to the shape's space
+// (A its linear part, B = A^-1, Frobenius norms |.|), the bound on the distance from the shape's centre beyond which a
+// line is certainly rejected:
+//   sphere, cube      the bounds of shape_cull_record with the composite M;
+//   closed or open cylinder with finite min, max (cylinder.rs:95-156): a computed root t satisfies the f32 quadratic
+//                     up to a perturbation of c by < 16u |o'|^2, and the point at that t has min < y < max up to 3u
+//                     (|o'| + |min| + |max|): accepted wall hits lie within radius sqrt(1 + 2e-6 |o'|^2) of the axis, cap
+//                     hits likewise (cylinder.rs:89-93) -- a sphere around the finite cylinder, inflated by
+//                     1e-5 (|o'|^2 + 1): the sphere's kq form;
+//   triangles         (their own transform identity, collected per space): accepted hits lie within
+//                     1.5 * 16u * K (|s| + L) of the triangle, K <= 1e4 |e1||e2||d'| (DESIGN.md "Auxiliary BVH"): a sphere
+//                     around the set's box, inflated by 2.4e-2 amax |d'| (|o' - c| + r + lmax): the kd terms;
+//   plane, cone, unbounded cylinder, anything non-finite: no record for any group above it.
+// Rounding of the k chained f32 transforms: k * 8e-6 * (cond (l + |c| + R) + |B| |t|), cond = max |B||A| along the chain.
+// ---------------------------------------------------------------------------------------------------------
+struct Aff {
+  double A[3][3], t[3];
+};
+inline Aff aff_identity() {
+  Aff r{};
+  r.A[0][0] = r.A[1][1] = r.A[2][2] = 1.0;
+  return r;
+}
+inline Aff aff_from(const RtXform& x) {
+  Aff r;
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) r.A[i][j] = x.m[4 * i + j];
+    r.t[i] = x.m[4 * i + 3];
+  }
+  return r;
+}
+inline Aff aff_after(const Aff& second, const Aff& first) {  // x -> second(first(x))
+  Aff r;
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) r.A[i][j] = second.A[i][0] * first.A[0][j] + second.A[i][1] * first.A[1][j] + second.A[i][2] * first.A[2][j];
+    r.t[i] = second.A[i][0] * first.t[0] + second.A[i][1] * first.t[1] + second.A[i][2] * first.t[2] + second.t[i];
+  }
+  return r;
+}
+inline double frob3(const double A[3][3]) {
+  double s = 0;
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) s += A[i][j] * A[i][j];
+  return std::sqrt(s);
+}
+inline bool inv3(const double A[3][3], double B[3][3]) {
+  double det = A[0][0] * (A[1][1] * A[2][2] - A[1][2] * A[2][1]) - A[0][1] * (A[1][0] * A[2][2] - A[1][2] * A[2][0]) +
+               A[0][2] * (A[1][0] * A[2][1] - A[1][1] * A[2][0]);
+  if (!std::isfinite(det) || !(std::fabs(det) > 1e-300)) return false;
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) {
+      int r1 = (c + 1) % 3, r2 = (c + 2) % 3, c1 = (r + 1) % 3, c2 = (r + 2) % 3;
+      B[r][c] = (A[r1][c1] * A[r2][c2] - A[r1][c2] * A[r2][c1]) / det;
+    }
+  return true;
+}
+// one bounded thing below a group, as the coefficients of its rejection bound around its own centre (record space)
+struct CullItem {
+  double c[3], R, q1, q0, kq, k1, k0, kd1, kd0;
+};
+// chain: M (record space -> item space), number of f32 transform steps, and the worst norms met along the chain
+struct Chain {
+  Aff M = aff_identity();
+  int steps = 0;
+  double cond = 1.0, nB_nt = 0.0;  // max |B_j||A_j|, max |B_j||t_j| over the partial products
+  bool ok = true;
+};
+inline Chain chain_then(const Chain& c, const RtXform& x) {
+  Chain r = c;
+  r.M = aff_after(aff_from(x), c.M);
+  r.steps = c.steps + 1;
+  double B[3][3];
+  if (!inv3(r.M.A, B)) {
+    r.ok = false;
+    return r;
+  }
+  const double nA = frob3(r.M.A), nB = frob3(B);
+  const double nt = std::sqrt(r.M.t[0] * r.M.t[0] + r.M.t[1] * r.M.t[1] + r.M.t[2] * r.M.t[2]);
+  r.cond = std::max(c.cond, nA * nB);
+  r.nB_nt = std::max(c.nB_nt, nB * nt);
+  r.ok = c.ok && std::isfinite(r.cond) && std::isfinite(r.nB_nt);
+  return r;
+}
+// kind: RT_SPHERE / RT_CUBE / RT_CYLINDER (yc, half height h) / RT_TRIANGLE (a set: centre cT, radius rT, amax, lmax)
+inline bool cull_item(const Chain& ch, uint32_t kind, const double centre_obj[3], double r_obj, double amax, double lmax,
+                      CullItem* out) {
+  if (!ch.ok) return false;
+  const Aff& M = ch.M;
+  double B[3][3];
+  if (!inv3(M.A, B)) return false;
+  const double nA = frob3(M.A), nB = frob3(B);
+  // centre in record space: B (centre_obj - t)
+  double d[3] = {centre_obj[0] - M.t[0], centre_obj[1] - M.t[1], centre_obj[2] - M.t[2]};
+  CullItem it{};
+  for (int r = 0; r < 3; r++) it.c[r] = B[r][0] * d[0] + B[r][1] * d[1] + B[r][2] * d[2];
+  const double ncp = std::sqrt(it.c[0] * it.c[0] + it.c[1] * it.c[1] + it.c[2] * it.c[2]);
+  const double nco = std::sqrt(centre_obj[0] * centre_obj[0] + centre_obj[1] * centre_obj[1] + centre_obj[2] * centre_obj[2]);
+  double btb[3][3] = {};
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++)
+      for (int k = 0; k < 3; k++) btb[i][j] += B[k][i] * B[k][j];
+  const double smax = std::sqrt(sym3_max_eig(btb)) * (1.0 + 1e-9);  // largest stretch of B
+  if (kind == RT_CUBE) {
+    double R = 0;
+    for (int k = 0; k < 8; k++) {
+      double q[3] = {k & 1 ? 1.0 : -1.0, k & 2 ? 1.0 : -1.0, k & 4 ? 1.0 : -1.0};
+      double d2 = 0;
+      for (int r = 0; r < 3; r++) {
+        double v = B[r][0] * q[0] + B[r][1] * q[1] + B[r][2] * q[2];
+        d2 += v * v;
+      }
+      R = std::max(R, std::sqrt(d2));
+    }
+    it.R = R;
+    it.k1 = 4e-4 * nB * nB * nA;
+    it.k0 = 4e-4 * nB * nB * std::sqrt(3.0);
+  } else if (kind == RT_SPHERE || kind == RT_CYLINDER) {
+    it.R = smax * r_obj;
+    // |o'|^2 <= 2 |A|^2 l^2 + 2 |centre_obj|^2  (o' - centre_obj = A (o - c))
+    it.kq = 2e-5 * nA * nA * nB;
+    it.q0 = nB * (2e-5 * nco * nco + 2e-5);
+  } else {  // triangle set
+    it.R = smax * r_obj;
+    it.kd1 = 2.4e-2 * amax * nB * nA * nA;
+    it.kd0 = 2.4e-2 * amax * nB * nA * (r_obj + lmax);
+  }
+  // rounding of the chained f32 transforms (and of the record's own centre)
+  const double k = std::max(1, ch.steps);
+  it.q1 += k * 8e-6 * ch.cond;
+  it.q0 += k * 8e-6 * (ch.cond * (ncp + it.R) + ch.nB_nt) + 1e-6 * (ncp + it.R);
+  it.R *= 1.0 + 1e-4;
+  const double v[] = {it.c[0], it.c[1], it.c[2], it.R, it.q1, it.q0, it.kq, it.k1, it.k0, it.kd1, it.kd0};
+  for (double x : v)
+    if (!std::isfinite(x) || std::fabs(x) > 1e30) return false;
+  *out = it;
+  return true;
+}
+struct NodeCull {
+  std::vector<float> recs;        // 12 floats per record
+  std::vector<uint32_t> rec_of;   // per node: record index or kNone
+};
+inline NodeCull build_node_cull(const RtScene* s) {
+  NodeCull out;
+  const uint32_t nn = s->n_nodes;
+  out.rec_of.assign(nn, kNone);
+  if (nn == 0) return out;
+  // identity triangles collected per space (the nearest transformed node at or above their group; nn = world space)
+  struct TriAgg {
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    double amax = 0, lmax = 0;
+    uint64_t n = 0;
+    bool ok = true;
+  };
+  std::vector<uint32_t> xf_nodes;  // transformed nodes, ascending
+  for (uint32_t i = 0; i < nn; i++)
+    if (s->nodes[i].xform) xf_nodes.push_back(i);
+  if (xf_nodes.empty()) return out;
+  std::vector<TriAgg> agg(nn);  // indexed by the space's node
+  std::vector<uint32_t> loose;  // shapes that are not identity triangles, ascending (grouped shapes only)
+  const uint32_t n_grouped = s->n_shapes - s->n_loose_shapes;
+  for (uint32_t i = 0; i < nn; i++) {
+    const RtNode& n = s->nodes[i];
+    for (uint32_t k = 0; k < n.n_shapes; k++) {
+      const uint32_t si = n.first_shape + k;
+      const RtShape& sh = s->shapes[si];
+      const uint32_t kind = sh.kind_flags & RT_SHAPE_KIND_MASK;
+      if (kind >= RT_TRIANGLE && sh.xform == 0 && n.next_xf >= 0) {
+        TriAgg& a = agg[n.next_xf];
+        const RtTriGeom& g = s->tri_geom[sh.prim];
+        double l1 = 0, l2 = 0, l3 = 0;
+        for (int c = 0; c < 3; c++) {
+          const double p1 = g.p1[c], p2 = p1 + g.e1[c], p3 = p1 + g.e2[c];
+          if (!std::isfinite(p1) || !std::isfinite(p2) || !std::isfinite(p3)) a.ok = false;
+          a.lo[c] = std::min(a.lo[c], std::min(p1, std::min(p2, p3)));
+          a.hi[c] = std::max(a.hi[c], std::max(p1, std::max(p2, p3)));
+          const double dd = (double)g.e2[c] - g.e1[c];
+          l1 += (double)g.e1[c] * g.e1[c], l2 += (double)g.e2[c] * g.e2[c], l3 += dd * dd;
+        }
+        a.amax = std::max(a.amax, std::sqrt(l1) * std::sqrt(l2));
+        a.lmax = std::max(a.lmax, std::sqrt(std::max(l1, std::max(l2, l3))));
+        a.n++;
+      } else if (n.next_xf >= 0) {
+        loose.push_back(si);
+      }
+    }
+  }
+  (void)n_grouped;
+  uint64_t budget = 4000000;  // chain evaluations over all records: beyond it the remaining groups go without
+  for (uint32_t i : xf_nodes) {
+    const RtNode& root = s->nodes[i];
+    std::vector<CullItem> items;
+    bool ok = true;
+    // chains of the transformed nodes of the subtree, in ascending (= DFS) order: a node's chain extends that of the
+    // nearest transformed node above it
+    const auto xb = std::lower_bound(xf_nodes.begin(), xf_nodes.end(), i);
+    const auto xe = std::lower_bound(xf_nodes.begin(), xf_nodes.end(), root.skip);
+    std::vector<Chain> chains(xe - xb);
+    auto chain_of = [&](uint32_t j) -> const Chain& { return chains[std::lower_bound(xb, xe, j) - xb]; };
+    for (auto it = xb; it != xe && ok; ++it) {
+      const uint32_t j = *it;
+      if (budget == 0) ok = false;
+      else budget--;
+      const RtNode& nj = s->nodes[j];
+      Chain base;  // record space
+      if (j != i) {
+        const int32_t up = nj.parent >= 0 ? s->nodes[nj.parent].next_xf : -1;
+        if (up < (int32_t)i) {
+          ok = false;
+          break;
+        }
+        base = chain_of((uint32_t)up);
+      }
+      Chain& c = chains[it - xb];
+      c = chain_then(base, s->xforms[nj.xform]);
+      ok = ok && c.ok;
+      const TriAgg& a = agg[j];
+      if (ok && a.n) {
+        if (!a.ok) {
+          ok = false;
+          break;
+        }
+        double cT[3], r2 = 0;
+        for (int q = 0; q < 3; q++) {
+          cT[q] = 0.5 * (a.lo[q] + a.hi[q]);
+          const double h = 0.5 * (a.hi[q] - a.lo[q]);
+          r2 += h * h;
+        }
+        CullItem ci;
+        ok = cull_item(c, RT_TRIANGLE, cT, std::sqrt(r2), a.amax, a.lmax, &ci);
+        if (ok) items.push_back(ci);
+      }
+    }
+    // the other shapes of the subtree, one by one
+    if (ok) {
+      const uint32_t s_lo = root.first_shape;
+      const uint32_t s_hi = root.skip < nn ? s->nodes[root.skip].first_shape : s->n_shapes - s->n_loose_shapes;
+      for (auto it = std::lower_bound(loose.begin(), loose.end(), s_lo); ok && it != loose.end() && *it < s_hi; ++it) {
+        if (budget == 0) ok = false;
+        else budget--;
+        const RtShape& sh = s->shapes[*it];
+        const uint32_t kind = sh.kind_flags & RT_SHAPE_KIND_MASK;
+        if (sh.parent < 0 || s->nodes[sh.parent].next_xf < (int32_t)i) {
+          ok = false;
+          break;
+        }
+        Chain c = chain_of((uint32_t)s->nodes[sh.parent].next_xf);
+        if (sh.xform) c = chain_then(c, s->xforms[sh.xform]);
+        CullItem ci;
+        const double zero[3] = {0, 0, 0};
+        if (kind == RT_SPHERE) {
+          ok = cull_item(c, RT_SPHERE, zero, 1.0, 0, 0, &ci);
+        } else if (kind == RT_CUBE) {
+          ok = cull_item(c, RT_CUBE, zero, std::sqrt(3.0), 0, 0, &ci);
+        } else if (kind == RT_CYLINDER && std::isfinite(sh.mn) && std::isfinite(sh.mx) && sh.mn <= sh.mx) {
+          const double yc[3] = {0, 0.5 * ((double)sh.mn + sh.mx), 0};
+          const double h = 0.5 * ((double)sh.mx - sh.mn);
+          ok = cull_item(c, RT_CYLINDER, yc, std::sqrt(1.0 + h * h), 0, 0, &ci);
+        } else if (kind >= RT_TRIANGLE) {
+          const RtTriGeom& g = s->tri_geom[sh.prim];
+          double lo[3], hi[3], cT[3], r2 = 0, l1 = 0, l2 = 0, l3 = 0;
+          for (int q = 0; q < 3; q++) {
+            const double p1 = g.p1[q], p2 = p1 + g.e1[q], p3 = p1 + g.e2[q];
+            lo[q] = std::min(p1, std::min(p2, p3)), hi[q] = std::max(p1, std::max(p2, p3));
+            cT[q] = 0.5 * (lo[q] + hi[q]);
+            r2 += 0.25 * (hi[q] - lo[q]) * (hi[q] - lo[q]);
+            const double dd = (double)g.e2[q] - g.e1[q];
+            l1 += (double)g.e1[q] * g.e1[q], l2 += (double)g.e2[q] * g.e2[q], l3 += dd * dd;
+          }
+          ok = cull_item(c, RT_TRIANGLE, cT, std::sqrt(r2), std::sqrt(l1) * std::sqrt(l2), std::sqrt(std::max(l1, std::max(l2, l3))), &ci);
+        } else {
+          ok = false;  // plane, cone, unbounded cylinder
+        }
+        if (ok) items.push_back(ci);
+      }
+    }
+    if (!ok) continue;
+    // one record around all items
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (const CullItem& it : items)
+      for (int q = 0; q < 3; q++) lo[q] = std::min(lo[q], it.c[q] - it.R), hi[q] = std::max(hi[q], it.c[q] + it.R);
+    double c[3] = {0, 0, 0}, R = 0, q1 = 0, kq = 0, k1 = 0, k0 = 0, kd1 = 0, kd0 = 0;
+    if (!items.empty())
+      for (int q = 0; q < 3; q++) c[q] = 0.5 * (lo[q] + hi[q]);
+    for (const CullItem& it : items) {
+      const double e = std::sqrt((it.c[0] - c[0]) * (it.c[0] - c[0]) + (it.c[1] - c[1]) * (it.c[1] - c[1]) + (it.c[2] - c[2]) * (it.c[2] - c[2]));
+      R = std::max(R, e + it.R + it.q1 * e + it.q0 + it.kq * e * e);
+      q1 = std::max(q1, it.q1 + 2.0 * it.kq * e);
+      kq = std::max(kq, it.kq);
+      k1 = std::max(k1, it.k1);
+      k0 = std::max(k0, it.k1 * e + it.k0);
+      kd1 = std::max(kd1, it.kd1);
+      kd0 = std::max(kd0, it.kd1 * e + it.kd0);
+    }
+    if (items.empty()) continue;
+    const double v[12] = {c[0], c[1], c[2], R, q1, 0, kq, k1, k0, kd1, kd0, 0};
+    bool fin = true;
+    for (double x : v) fin = fin && std::isfinite(x) && std::fabs(x) < 1e30;
+    if (!fin) continue;
+    out.rec_of[i] = (uint32_t)(out.recs.size() / 12);
+    for (int q = 0; q < 3; q++) out.recs.push_back((float)v[q]);
+    for (int q = 3; q < 12; q++) out.recs.push_back(v[q] < 0 ? (float)v[q] : std::nextafter((float)v[q], INFINITY));
+  }
+  return out;
+}
 
 }  // namespace rtaccel

@@ -28,6 +28,7 @@
 #define RT_SHAPE_CULLABLE 0x40u  // device copy of a shape: `prim` holds the index of its cull record
 #define RT_NODE_AUX 0x4u      // device copy only: this node is the root of a subtree covered by an auxiliary BVH
 #define RT_NODE_HAS_NOSHADOW 0x8u  // device copy only: a shape with shadow() == false lives in this subtree
+#define RT_NODE_CULLREC 0x10u     // device copy only (transformed nodes): the idrun slot holds the index of the subtree's cull record
 #ifndef RT_CONE_MIN_PAD
 #define RT_CONE_MIN_PAD 0.125f  // aux BVH: worst-case pad / longest triangle edge above which the cone bound is evaluated
 #endif
@@ -114,6 +115,7 @@ struct Scene {
   const RtLight* lights;
   const float4* aux_nodes;  // library-built auxiliary BVHs (rt_accel.h): 5 float4 per node
   const float4* shape_cull;  // cull spheres of cubes / spheres (rt_accel.h shape_cull_record): 3 float4 per record
+  const float4* node_cull;   // cull records of transformed groups (rt_accel.h build_node_cull): 3 float4 per record
   const float4* aux_tris;   // their leaf triangles: 3 float4 per triangle, p1.w = offset in the group
   uint32_t n_shapes, n_nodes, n_csg_roots, n_lights, n_loose, recursion_limit;
   uint32_t flags;  // RT_RENDER_*
@@ -1106,23 +1108,39 @@ __device__ RT_WI_INLINE void world_intersect(const Scene& sc, const Ray& ray, Si
           cur = q >= 0 ? ray_in_space_of(sc, q, ray) : ray;
           leave_at = q >= 0 ? cst(sc.nodes)[q].skip : 0xFFFFFFFFu;
         }
-        if (COUNT) cn.node_visits++;
         RT_UTIL(2);
-        if (COUNT && xform) cn.xforms++;
-        if (xform) {
-          cur = xf_ray(sc, xform, cur);
-          leave_at = skip;
+        bool culled = false;
+        if ((flags & RT_NODE_CULLREC) && prune) {
+          // cull record of the whole subtree, in the space `cur` is in (rt_accel.h build_node_cull): a line this far
+          // from everything below the group is one that none of their f32 tests accepts.  Skips the transform and the
+          // reference's box test; NaN => not culled.
+          const f4n RT_CONST_AS* q = cst(reinterpret_cast<const f4n*>(sc.node_cull)) + 3u * (size_t)w3.z;
+          const f4n c0 = q[0], c1 = q[1], c2 = q[2];
+          const V3 oc = v3(c0.x, c0.y, c0.z) - cur.o;
+          const V3 cr = cross(oc, cur.d);
+          const float ol2 = dot(oc, oc);
+          const float dl = __builtin_amdgcn_sqrtf(dot(cur.d, cur.d)), ol = __builtin_amdgcn_sqrtf(ol2);
+          const float thr = (dl * (((c0.w + c1.x * ol) + c1.z * ol2) + dl * (c2.y * ol + c2.z)) + (c1.w * ol + c2.x)) * 1.0001f;
+          culled = dot(cr, cr) > thr * thr;
         }
-        float tmin, tmax;
-        V3 bmin = v3(__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z));
-        V3 bmax = v3(__uint_as_float(w1.x), __uint_as_float(w1.y), __uint_as_float(w1.z));
-        descend = slab_decided(cur, bmin, bmax, tmin, tmax);  // groups.rs:111-113
-        if (descend && prune && (flags & RT_NODE_PRUNABLE)) {
-          // Distance pruning (not in the reference): a box that truly encloses its subtree cannot
-          // hold a hit beyond its exit or before its entry; margins cover f32 rounding of t.
-          float lim = sink.limit();
-          if (tmin > lim + (1e-4f * __builtin_fabsf(lim) + 1e-4f)) descend = false;
-          if (!sink.wants_negative() && tmax < -(1e-4f * __builtin_fabsf(tmax) + 1e-4f)) descend = false;
+        if (!culled) {
+          if (COUNT) cn.node_visits++;
+          if (COUNT && xform) cn.xforms++;
+          if (xform) {
+            cur = xf_ray(sc, xform, cur);
+            leave_at = skip;
+          }
+          float tmin, tmax;
+          V3 bmin = v3(__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z));
+          V3 bmax = v3(__uint_as_float(w1.x), __uint_as_float(w1.y), __uint_as_float(w1.z));
+          descend = slab_decided(cur, bmin, bmax, tmin, tmax);  // groups.rs:111-113
+          if (descend && prune && (flags & RT_NODE_PRUNABLE)) {
+            // Distance pruning (not in the reference): a box that truly encloses its subtree cannot
+            // hold a hit beyond its exit or before its entry; margins cover f32 rounding of t.
+            float lim = sink.limit();
+            if (tmin > lim + (1e-4f * __builtin_fabsf(lim) + 1e-4f)) descend = false;
+            if (!sink.wants_negative() && tmax < -(1e-4f * __builtin_fabsf(tmax) + 1e-4f)) descend = false;
+          }
         }
       }
       // device copy of a node: the slot of n_children holds the auxiliary BVH of the subtree (RT_NODE_AUX)
@@ -1212,7 +1230,7 @@ __device__ inline V3 normal_to_world(const Scene& sc, uint32_t shape_xform, int 
   int g = parent;
   while (g >= 0) {
     const RtNode RT_CONST_AS& nd = cst(sc.nodes)[g];
-    n = renorm_identity(n, nd.idrun);
+    n = renorm_identity(n, nd.xform ? 0u : nd.idrun);  // (a transformed node's idrun is 0; the device copy reuses the slot)
     int q = nd.next_xf;
     if (q < 0) break;
     n = normalize(xf_normal(cst(sc.xforms)[cst(sc.nodes)[q].xform].m, n));

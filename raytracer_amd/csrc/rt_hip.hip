@@ -696,6 +696,16 @@ int rt_scene_create(RtContext* ctx, const RtScene* s, RtDeviceScene** out) {
         nodes[i].n_children = acc.gate_next[i];
       }
     }
+    // cull records of transformed groups: the record index rides in the idrun slot (0 for every transformed node)
+    rtaccel::NodeCull nc = rtaccel::build_node_cull(s);
+    for (uint32_t i = 0; i < s->n_nodes; i++)
+      if (nc.rec_of[i] != rtaccel::kNone) {
+        nodes[i].idrun = nc.rec_of[i];
+        nodes[i].flags |= RT_NODE_CULLREC;
+      }
+    const float* dnc = nullptr;
+    UP(dnc, nc.recs.data(), nc.recs.size())
+    d.node_cull = reinterpret_cast<const float4*>(dnc);
     const rtaccel::Node* an = nullptr;
     const rtaccel::Tri* at = nullptr;
     UP(d.nodes, nodes.data(), nodes.size())
