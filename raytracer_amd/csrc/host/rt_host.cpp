@@ -16,12 +16,15 @@
 #include <chrono>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <limits>
 #include <map>
 #include <memory>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -258,6 +261,19 @@ struct HTri {
   P3 p1, p2, p3, e1, e2;
   P3 n1, n2, n3;  // flat: n1 = normal
 };
+// A triangle mesh kept ONCE however many groups instance it.  The reference re-parses the OBJ file and builds new
+// Triangle shapes for every `obj:` use (scene.rs:593-599); their values are equal, so everything derived from the
+// values alone -- Triangle::new's edges and normal, parent_space_bounds, the value class of the geometry -- is computed
+// once here, and groups hold triangle INDICES into the mesh (HGroup::mtris) instead of shapes.
+struct HMesh {
+  uint64_t hash = 0;               // of the inputs, to recognise the same mesh handed in again
+  std::vector<float> in_pos, in_nrm;
+  std::vector<int32_t> in_vidx, in_nidx;
+  std::vector<HTri> tris;
+  std::vector<uint8_t> smooth;     // RTB_SMOOTH_TRIANGLE or RTB_TRIANGLE per triangle (obj.rs:24-36)
+  std::vector<Box> box;            // parent_space_bounds of each triangle (identity transform, shapes.rs:318-320)
+  std::vector<uint32_t> gid;       // value class of the triangle's geometry (TriValueTable), RT_VCLASS_NEVER if it holds a NaN
+};
 struct HShape {
   uint8_t kind = RTB_SPHERE;
   bool shadow = true, closed = false;
@@ -276,6 +292,22 @@ struct HGroup {
   int parent = -1;
   bool cached = false;
   Box bounds;
+  // triangles of a mesh, by index, in insertion order (a group holds either these or `shapes`, never both: adding a
+  // shape to a mesh group first turns its triangles into shapes).  All share the material `mmat`.
+  int mesh = -1;
+  std::vector<uint32_t> mtris;
+  RtbMaterial mmat{};
+  bool fresh_mesh = false;  // exactly what group_add_mesh made: every triangle of the mesh in order, nothing else
+};
+// The result of `divide` on a fresh mesh group (groups.rs:284-299), kept so that the next instance of the same mesh
+// with the same threshold is a copy of the tree instead of a second partition of 871 k triangles: the partition
+// depends on the triangles' boxes only, never on the instance's material or on any transform above it.
+struct DivNode {
+  std::vector<uint32_t> mtris;
+  std::vector<int> children;  // indices into DivTemplate::nodes
+};
+struct DivTemplate {
+  std::vector<DivNode> nodes;  // [0] = the mesh group itself
 };
 struct HCsg {
   int op = 0;
@@ -343,11 +375,16 @@ struct ClassTable {
     std::vector<uint32_t> ns(cap, 0);
     for (uint32_t id = 0; id < next; id++) {
       uint64_t w = where[id];
+      if ((w & 0xFFFF) == 0) continue;  // an id handed out by fresh(): it has no key
       size_t i = hash(arena.data() + (w >> 16), (uint32_t)(w & 0xFFFF)) & (cap - 1);
       while (ns[i]) i = (i + 1) & (cap - 1);
       ns[i] = id + 1;
     }
     slots.swap(ns);
+  }
+  uint32_t fresh() {  // a new class id that no key maps to (the caller keeps its own index to it)
+    where.push_back(0);
+    return next++;
   }
   uint32_t get(const KeyBuilder& k) {
     if (k.nan) return RT_VCLASS_NEVER;
@@ -363,6 +400,92 @@ struct ClassTable {
     arena.insert(arena.end(), k.bytes, k.bytes + k.len);
     slots[i] = next + 1;
     return next++;
+  }
+};
+
+// Value classes of triangle GEOMETRY: ids in first-seen order; two triangles get the same id iff the reference's
+// derived `==` on Triangle / SmoothTriangle holds for them apart from material, transform and shadow (p1, p2, p3, e1, e2
+// and normal / n1..n3, triangle.rs:14-27; a flat and a smooth triangle are different enum variants, never equal).
+// Entries point at the triangle itself instead of copying its bytes.
+struct TriValueTable {
+  std::vector<const HTri*> rep;    // per id: a triangle with that value
+  std::vector<uint8_t> rep_smooth;
+  std::vector<uint64_t> rep_hash;
+  std::vector<uint32_t> slots;     // id + 1, 0 = empty
+  static void words(const HTri& t, bool smooth, uint32_t* w, int* n, bool* nan) {
+    const P3* ps[8] = {&t.p1, &t.p2, &t.p3, &t.e1, &t.e2, &t.n1, &t.n2, &t.n3};
+    const int np = smooth ? 8 : 6;
+    *nan = false;
+    int k = 0;
+    for (int i = 0; i < np; i++) {
+      float v[3] = {ps[i]->x, ps[i]->y, ps[i]->z};
+      for (float x : v) {
+        if (std::isnan(x)) *nan = true;
+        if (x == 0.f) x = 0.f;  // -0 == +0
+        std::memcpy(&w[k++], &x, 4);
+      }
+    }
+    w[k++] = smooth ? 1u : 0u;
+    *n = k;
+  }
+  static uint64_t hash(const uint32_t* w, int n) {
+    uint64_t h = 0x9E3779B97F4A7C15ull;
+    for (int i = 0; i < n; i++) {
+      h = (h ^ w[i]) * 0xFF51AFD7ED558CCDull;
+      h ^= h >> 29;
+    }
+    return h;
+  }
+  void grow() {
+    size_t cap = slots.empty() ? 4096 : slots.size() * 2;
+    std::vector<uint32_t> ns(cap, 0);
+    for (uint32_t id = 0; id < rep.size(); id++) {
+      size_t i = rep_hash[id] & (cap - 1);
+      while (ns[i]) i = (i + 1) & (cap - 1);
+      ns[i] = id + 1;
+    }
+    slots.swap(ns);
+  }
+  void reserve(size_t more) {
+    while ((rep.size() + more + 1) * 2 > slots.size()) grow();
+  }
+  // hash of a triangle's value, or 0 with *nan set (computed ahead, in parallel, for whole meshes)
+  static uint64_t value_hash(const HTri& t, bool smooth, bool* nan) {
+    uint32_t w[25];
+    int n;
+    words(t, smooth, w, &n, nan);
+    return hash(w, n);
+  }
+  // `t` must stay where it is for the life of the table (mesh triangles and the world's triangle arena do)
+  uint32_t get(const HTri& t, bool smooth) {
+    bool nan;
+    const uint64_t h = value_hash(t, smooth, &nan);
+    return get_hashed(t, smooth, h, nan);
+  }
+  uint32_t get_hashed(const HTri& t, bool smooth, uint64_t h, bool nan) {
+    if (nan) return RT_VCLASS_NEVER;
+    if ((rep.size() + 1) * 2 > slots.size()) grow();
+    const size_t mask = slots.size() - 1;
+    uint32_t w[25];
+    int n = 0;
+    size_t i = h & mask;
+    while (slots[i]) {
+      const uint32_t id = slots[i] - 1;
+      if (rep_hash[id] == h && (rep_smooth[id] != 0) == smooth) {
+        uint32_t w2[25];
+        int n2;
+        bool nan2;
+        if (n == 0) words(t, smooth, w, &n, &nan2);
+        words(*rep[id], smooth, w2, &n2, &nan2);
+        if (std::memcmp(w, w2, 4 * (size_t)n) == 0) return id;
+      }
+      i = (i + 1) & mask;
+    }
+    rep.push_back(&t);
+    rep_hash.push_back(h);
+    rep_smooth.push_back(smooth ? 1 : 0);
+    slots[i] = (uint32_t)rep.size();
+    return (uint32_t)rep.size() - 1;
   }
 };
 
@@ -387,7 +510,11 @@ struct Flat {
 
 struct RtbWorld {
   std::vector<HShape> shapes;  // arena: detached shapes and every placed copy
-  std::vector<HTri> tris;
+  std::deque<HTri> tris;       // (a deque: TriValueTable keeps pointers to its elements)
+  std::vector<uint32_t> tri_gid;  // per entry of `tris`: value class of its geometry
+  std::vector<std::unique_ptr<HMesh>> meshes;
+  TriValueTable tri_values;
+  std::map<std::pair<int, int>, DivTemplate> div_cache;  // (mesh, threshold) -> the divided tree
   std::vector<HGroup> groups;
   std::vector<HCsg> csgs;
   std::vector<HUv> uvs;
@@ -460,7 +587,34 @@ struct RtbWorld {
   }
 
   // ---- groups (src/groups.rs) -----------------------------------------------------------
-  int group_len(int g) const { return (int)(groups[g].shapes.size() + groups[g].children.size()); }
+  int group_len(int g) const { return (int)(groups[g].shapes.size() + groups[g].mtris.size() + groups[g].children.size()); }
+  // a mesh group's triangles as ordinary shapes (what the reference holds anyway), for the rare group that mixes a
+  // mesh with other shapes; keeps the insertion order: the triangles came first
+  void materialise(int g) {
+    HGroup& gr = groups[g];
+    if (gr.mtris.empty()) return;
+    const HMesh& m = *meshes[gr.mesh];
+    std::vector<uint32_t> made;
+    made.reserve(gr.mtris.size());
+    for (uint32_t t : gr.mtris) {
+      tris.push_back(m.tris[t]);
+      tri_gid.push_back(m.gid[t]);
+      HShape s;
+      s.kind = m.smooth[t];
+      s.mat = gr.mmat;
+      s.tri = (int)tris.size() - 1;
+      s.parent = g;
+      s.psb = m.box[t];
+      shapes.push_back(s);
+      made.push_back((uint32_t)shapes.size() - 1);
+    }
+    HGroup& g2 = groups[g];
+    made.insert(made.end(), g2.shapes.begin(), g2.shapes.end());
+    g2.shapes.swap(made);
+    g2.mtris.clear();
+    g2.mesh = -1;
+    g2.fresh_mesh = false;
+  }
   Box group_bounds(int g) const {  // :166-174
     if (groups[g].cached) return groups[g].bounds;
     return make_bounds(g);
@@ -469,6 +623,10 @@ struct RtbWorld {
     const HGroup& gr = groups[g];
     Box bb;
     for (uint32_t s : gr.shapes) box_merge(bb, shapes[s].psb);
+    if (!gr.mtris.empty()) {
+      const HMesh& m = *meshes[gr.mesh];
+      for (uint32_t t : gr.mtris) box_merge(bb, m.box[t]);
+    }
     for (int c : gr.children) {
       if (gr.parent < 0) bb = box_transform(bb, gr.xf);  // the reference's root-with-children quirk
       box_merge(bb, group_bounds(c));
@@ -498,6 +656,25 @@ struct RtbWorld {
         keep.push_back(s);
     }
     groups[g].shapes = std::move(keep);
+    // the triangles of a mesh group, by the same rule on their boxes
+    std::vector<uint32_t> lt, rt;
+    const int mesh = groups[g].mesh;
+    const RtbMaterial mmat = groups[g].mmat;
+    if (!groups[g].mtris.empty()) {
+      const HMesh& m = *meshes[mesh];
+      std::vector<uint32_t> allt, keept;
+      allt.swap(groups[g].mtris);
+      for (uint32_t t : allt) {
+        if (box_has_box(lb, m.box[t]))
+          lt.push_back(t);
+        else if (box_has_box(rb, m.box[t]))
+          rt.push_back(t);
+        else
+          keept.push_back(t);
+      }
+      groups[g].mtris = std::move(keept);
+      groups[g].fresh_mesh = false;
+    }
     std::vector<int> kids;
     kids.swap(groups[g].children);
     std::vector<int> lk, rk, keepk;
@@ -513,18 +690,113 @@ struct RtbWorld {
     groups[g].children = std::move(keepk);
     int L = new_group();
     groups[L].shapes = std::move(ls);
+    groups[L].mtris = std::move(lt);
+    groups[L].mesh = mesh;
+    groups[L].mmat = mmat;
     groups[L].children = lk;
     for (uint32_t s : groups[L].shapes) shapes[s].parent = L;
     for (int c : lk) groups[c].parent = L;
     int R = new_group();
     groups[R].shapes = std::move(rs);
+    groups[R].mtris = std::move(rt);
+    groups[R].mesh = mesh;
+    groups[R].mmat = mmat;
     groups[R].children = rk;
     for (uint32_t s : groups[R].shapes) shapes[s].parent = R;
     for (int c : rk) groups[c].parent = R;
     *lo_out = L;
     *hi_out = R;
   }
+  int snapshot(int g, DivTemplate& t) const {
+    const int me = (int)t.nodes.size();
+    t.nodes.emplace_back();
+    t.nodes[me].mtris = groups[g].mtris;
+    for (int c : groups[g].children) {
+      const int k = snapshot(c, t);
+      t.nodes[me].children.push_back(k);
+    }
+    return me;
+  }
+  void instantiate(int g, const DivTemplate& t, int node) {
+    groups[g].mtris = t.nodes[node].mtris;
+    groups[g].fresh_mesh = false;
+    for (int k : t.nodes[node].children) {
+      const int c = new_group();
+      groups[c].mesh = groups[g].mesh;
+      groups[c].mmat = groups[g].mmat;
+      attach_child(g, c);
+      instantiate(c, t, k);
+    }
+  }
+  // `divide` (groups.rs:284-299) of a group that holds only triangles `tris` of mesh `m`, as a template: partition if
+  // threshold <= len (groups.rs:285), attach the non-empty halves, divide them.  Every group met on the way has no
+  // children when it is partitioned, so its bounds are the union of its triangles' boxes.  The halves are independent:
+  // the top levels run on separate threads (par), each into a template of its own, appended left then right.
+  void divide_template(const HMesh& m, std::vector<uint32_t> tris, int threshold, DivTemplate& t, int par) const {
+    const int me = (int)t.nodes.size();
+    t.nodes.emplace_back();
+    if (threshold <= (int)tris.size()) {
+      Box bb;
+      for (uint32_t q : tris) box_merge(bb, m.box[q]);
+      Box lb, rb;
+      box_split(bb, &lb, &rb);
+      std::vector<uint32_t> lt, rt, keep;
+      for (uint32_t q : tris) {
+        if (box_has_box(lb, m.box[q]))
+          lt.push_back(q);
+        else if (box_has_box(rb, m.box[q]))
+          rt.push_back(q);
+        else
+          keep.push_back(q);
+      }
+      tris.swap(keep);
+      std::vector<uint32_t>().swap(keep);
+      auto child = [&](std::vector<uint32_t>& sub, DivTemplate& into, int p) {
+        const int k = (int)into.nodes.size();
+        divide_template(m, std::move(sub), threshold, into, p);
+        return k;
+      };
+      if (par > 0 && lt.size() + rt.size() >= 65536 && !lt.empty() && !rt.empty()) {
+        DivTemplate tl, tr;
+        std::thread th([&]() { child(lt, tl, par - 1); });
+        child(rt, tr, par - 1);
+        th.join();
+        for (DivTemplate* sub : {&tl, &tr}) {
+          const int off = (int)t.nodes.size();
+          t.nodes[me].children.push_back(off);
+          for (DivNode& n : sub->nodes) {
+            for (int& c : n.children) c += off;
+            t.nodes.push_back(std::move(n));
+          }
+        }
+      } else {
+        if (!lt.empty()) {
+          const int k = child(lt, t, 0);
+          t.nodes[me].children.push_back(k);
+        }
+        if (!rt.empty()) {
+          const int k = child(rt, t, 0);
+          t.nodes[me].children.push_back(k);
+        }
+      }
+    }
+    t.nodes[me].mtris = std::move(tris);
+  }
   void divide(int g, int threshold) {  // :284-299
+    // a mesh group exactly as group_add_mesh made it, already attached (so make_bounds' null-parent quirk cannot
+    // apply anywhere below): its divided tree depends on (mesh, threshold) only -- built once as a template
+    // (divide_template, the same rule on the same boxes), copied for every instance
+    if (groups[g].fresh_mesh && groups[g].parent >= 0 && groups[g].shapes.empty() && groups[g].children.empty()) {
+      const std::pair<int, int> key(groups[g].mesh, threshold);
+      auto it = div_cache.find(key);
+      if (it == div_cache.end()) {
+        DivTemplate t;
+        divide_template(*meshes[groups[g].mesh], groups[g].mtris, threshold, t, 4);
+        it = div_cache.emplace(key, std::move(t)).first;
+      }
+      instantiate(g, it->second, 0);
+      return;
+    }
     if (threshold <= group_len(g)) {
       int L, R;
       partition(g, &L, &R);
@@ -554,9 +826,73 @@ struct Flattener {
   std::unordered_map<uint32_t, uint32_t> material_slot;  // material class -> materials[] index
   std::vector<int> uv_class_of, pattern_class_of;
   std::vector<Box> true_box;  // per node, conservative box of the subtree in the node's space
+  // Value classes of triangles: (kind, transform, material class, shadow) is interned once per group, the geometry's
+  // class (TriValueTable) indexes a table per such triple.  Equal <=> the reference's Shape == Shape, as for every other
+  // shape, without hashing the 100-byte value of each of millions of mesh triangles per instance.
+  ClassTable triple_classes;
+  std::vector<std::vector<uint32_t>> triple_map;
+  static constexpr uint32_t kUnset = 0xFFFFFFFEu;
+  // Triangle data already emitted, by (mesh, sequence of triangle indices): instances of one mesh, divided the same
+  // way, share their tri_geom / tri_normals entries (a node's own triangles are a contiguous run of them).
+  struct Run {
+    int mesh;
+    const std::vector<uint32_t>* seq;
+    uint32_t first_tri;
+    Box box;  // union of the triangles' parent_space_bounds
+  };
+  std::unordered_map<uint64_t, std::vector<Run>> runs;
+  std::unordered_map<uint32_t, std::pair<uint32_t, uint32_t>> mesh_triples;  // material class -> (flat, smooth) triple ids
 
+  double t_loop = 0, t_run = 0;
   Flattener(RtbWorld& w_, Flat& f_) : w(w_), f(f_) {}
 
+  uint32_t triple_id(uint32_t kind, const M4& xf, uint32_t mclass, bool shadow) {
+    if (mclass == RT_VCLASS_NEVER) return RT_VCLASS_NEVER;
+    KeyBuilder k;
+    k.u(kind), k.fs(xf.a, 16), k.u(mclass), k.u(shadow ? 1 : 0);
+    const uint32_t tid = triple_classes.get(k);
+    if (tid != RT_VCLASS_NEVER && tid >= triple_map.size()) triple_map.resize(tid + 1);
+    return tid;
+  }
+  uint32_t tri_vclass(uint32_t tid, uint32_t gid) {
+    if (tid == RT_VCLASS_NEVER || gid == RT_VCLASS_NEVER) return RT_VCLASS_NEVER;
+    std::vector<uint32_t>& mp = triple_map[tid];
+    if (gid >= mp.size()) mp.resize(std::max<size_t>(gid + 1, w.tri_values.rep.size()), kUnset);
+    if (mp[gid] == kUnset) mp[gid] = shape_classes.fresh();
+    return mp[gid];
+  }
+  static void fill_tri(const HTri& t, RtTriGeom* g, RtTriNormals* n) {
+    *g = RtTriGeom{};
+    *n = RtTriNormals{};
+    g->p1[0] = t.p1.x, g->p1[1] = t.p1.y, g->p1[2] = t.p1.z;
+    g->e1[0] = t.e1.x, g->e1[1] = t.e1.y, g->e1[2] = t.e1.z;
+    g->e2[0] = t.e2.x, g->e2[1] = t.e2.y, g->e2[2] = t.e2.z;
+    n->n1[0] = t.n1.x, n->n1[1] = t.n1.y, n->n1[2] = t.n1.z;
+    n->n2[0] = t.n2.x, n->n2[1] = t.n2.y, n->n2[2] = t.n2.z;
+    n->n3[0] = t.n3.x, n->n3[1] = t.n3.y, n->n3[2] = t.n3.z;
+  }
+  const Run& geometry_run(int mesh, const std::vector<uint32_t>& seq) {
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)mesh;
+    for (uint32_t t : seq) {
+      h = (h ^ t) * 0xFF51AFD7ED558CCDull;
+      h ^= h >> 29;
+    }
+    std::vector<Run>& bucket = runs[h];
+    for (const Run& r : bucket)
+      if (r.mesh == mesh && r.seq->size() == seq.size() && std::memcmp(r.seq->data(), seq.data(), seq.size() * 4) == 0)
+        return r;
+    const HMesh& m = *w.meshes[mesh];
+    const uint32_t first = (uint32_t)f.tri_geom.size();
+    f.tri_geom.resize(first + seq.size());
+    f.tri_normals.resize(first + seq.size());
+    Box mb;
+    for (size_t k = 0; k < seq.size(); k++) {
+      fill_tri(m.tris[seq[k]], &f.tri_geom[first + k], &f.tri_normals[first + k]);
+      box_merge(mb, m.box[seq[k]]);
+    }
+    bucket.push_back(Run{mesh, &seq, first, mb});
+    return bucket.back();
+  }
   uint32_t xform_index(const M4& inv, bool identity) {
     if (identity) return 0;
     std::vector<uint32_t> key(12);
@@ -630,7 +966,23 @@ struct Flattener {
   }
 
   // material -> (materials[] index, value class)
+  RtbMaterial last_mat{};
+  uint32_t last_index = 0, last_class = 0;
+  bool have_last = false;
   void material(const RtbMaterial& m, uint32_t* index, uint32_t* vclass) {
+    // the same material as the call before (every sub-group of a divided mesh): same answer, unless it holds a NaN
+    if (have_last && last_class != RT_VCLASS_NEVER && std::memcmp(&m, &last_mat, sizeof(m)) == 0) {
+      *index = last_index;
+      *vclass = last_class;
+      return;
+    }
+    material_slow(m, index, vclass);
+    last_mat = m;
+    last_index = *index;
+    last_class = *vclass;
+    have_last = true;
+  }
+  void material_slow(const RtbMaterial& m, uint32_t* index, uint32_t* vclass) {
     KeyBuilder k;
     k.fs(m.color, 3);
     k.f(m.ambient), k.f(m.diffuse), k.f(m.specular), k.f(m.shininess), k.f(m.reflective), k.f(m.transparency),
@@ -678,25 +1030,16 @@ struct Flattener {
       // -inf/+inf compare equal to themselves; keep their bits
       k.f(s.mn), k.f(s.mx), k.u(s.closed ? 1 : 0);
     } else if (s.kind >= RTB_TRIANGLE) {
-      const HTri& t = w.tris[s.tri];
-      RtTriGeom g{};
-      g.p1[0] = t.p1.x, g.p1[1] = t.p1.y, g.p1[2] = t.p1.z;
-      g.e1[0] = t.e1.x, g.e1[1] = t.e1.y, g.e1[2] = t.e1.z;
-      g.e2[0] = t.e2.x, g.e2[1] = t.e2.y, g.e2[2] = t.e2.z;
-      RtTriNormals n{};
-      n.n1[0] = t.n1.x, n.n1[1] = t.n1.y, n.n1[2] = t.n1.z;
-      n.n2[0] = t.n2.x, n.n2[1] = t.n2.y, n.n2[2] = t.n2.z;
-      n.n3[0] = t.n3.x, n.n3[1] = t.n3.y, n.n3[2] = t.n3.z;
+      RtTriGeom g;
+      RtTriNormals n;
+      fill_tri(w.tris[s.tri], &g, &n);
       r.prim = (uint32_t)f.tri_geom.size();
       f.tri_geom.push_back(g);
       f.tri_normals.push_back(n);
-      // Triangle == compares p1,p2,p3,e1,e2 and normal / n1..n3 (triangle.rs:14-27)
-      const P3* ps[5] = {&t.p1, &t.p2, &t.p3, &t.e1, &t.e2};
-      for (auto p : ps) k.f(p->x), k.f(p->y), k.f(p->z);
-      k.f(t.n1.x), k.f(t.n1.y), k.f(t.n1.z);
-      if (s.kind == RTB_SMOOTH_TRIANGLE) {
-        k.f(t.n2.x), k.f(t.n2.y), k.f(t.n2.z), k.f(t.n3.x), k.f(t.n3.y), k.f(t.n3.z);
-      }
+      // Triangle == compares p1,p2,p3,e1,e2 and normal / n1..n3 (triangle.rs:14-27): the geometry's class
+      r.vclass = k.nan ? RT_VCLASS_NEVER : tri_vclass(triple_id(s.kind, s.xf, mclass, s.shadow), w.tri_gid[s.tri]);
+      f.shapes.push_back(r);
+      return (uint32_t)f.shapes.size() - 1;
     }
     r.vclass = shape_classes.get(k);
     f.shapes.push_back(r);
@@ -767,7 +1110,7 @@ struct Flattener {
     uint32_t xf = xform_index(gr.inv, identity);
     uint32_t first_shape = (uint32_t)f.shapes.size();
     uint32_t first_tri = (uint32_t)f.tri_geom.size();
-    bool all_tris = !gr.shapes.empty();
+    bool all_tris = !gr.shapes.empty() || !gr.mtris.empty();
     Box tb;   // true (conservative) box
     Box bb;   // the reference's make_bounds (groups.rs:176-188), recomputed with final parent state
     for (uint32_t s : gr.shapes) {
@@ -777,7 +1120,59 @@ struct Flattener {
       box_merge(tb, w.true_psb(hs));
       box_merge(bb, hs.psb);
     }
-    uint32_t n_shapes = (uint32_t)gr.shapes.size();
+    if (!gr.mtris.empty()) {  // the triangles of a mesh group, in bulk (a group holds these or shapes, never both)
+      const HMesh& m = *w.meshes[gr.mesh];
+      auto T1 = std::chrono::steady_clock::now();
+      const Run& run = geometry_run(gr.mesh, gr.mtris);
+      t_run += std::chrono::duration<double>(std::chrono::steady_clock::now() - T1).count();
+      first_tri = run.first_tri;
+      uint32_t mat_index, mclass;
+      material(gr.mmat, &mat_index, &mclass);
+      auto tids = mesh_triples.find(mclass);
+      if (tids == mesh_triples.end()) {
+        const M4 ident = m4_identity();
+        tids = mesh_triples.emplace(mclass, std::make_pair(triple_id(RTB_TRIANGLE, ident, mclass, true),
+                                                           triple_id(RTB_SMOOTH_TRIANGLE, ident, mclass, true))).first;
+      }
+      const uint32_t tid_flat = tids->second.first, tid_smooth = tids->second.second;
+      uint32_t* map_flat = nullptr;
+      uint32_t* map_smooth = nullptr;
+      const size_t n_gid = w.tri_values.rep.size();
+      if (tid_flat != RT_VCLASS_NEVER) {
+        if (triple_map[tid_flat].size() < n_gid) triple_map[tid_flat].resize(n_gid, kUnset);
+        if (triple_map[tid_smooth].size() < n_gid) triple_map[tid_smooth].resize(n_gid, kUnset);
+        map_flat = triple_map[tid_flat].data();
+        map_smooth = triple_map[tid_smooth].data();
+      }
+      const size_t base = f.shapes.size();
+      f.shapes.resize(base + gr.mtris.size());
+      const Box mb = run.box;
+      auto T0 = std::chrono::steady_clock::now();
+      for (size_t k = 0; k < gr.mtris.size(); k++) {
+        const uint32_t t = gr.mtris[k];
+        RtShape& r = f.shapes[base + k];
+        const bool smooth = m.smooth[t] == RTB_SMOOTH_TRIANGLE;
+        r.kind_flags = m.smooth[t] | RT_SHAPE_SHADOW;
+        r.xform = 0;
+        r.material = mat_index;
+        r.parent = (int32_t)idx;
+        uint32_t vc = RT_VCLASS_NEVER;
+        const uint32_t gid = m.gid[t];
+        if (map_flat && gid != RT_VCLASS_NEVER) {
+          uint32_t& slot = (smooth ? map_smooth : map_flat)[gid];
+          if (slot == kUnset) slot = shape_classes.fresh();
+          vc = slot;
+        }
+        r.vclass = vc;
+        r.prim = first_tri + (uint32_t)k;
+        r.mn = -kInf;
+        r.mx = kInf;
+      }
+      t_loop += std::chrono::duration<double>(std::chrono::steady_clock::now() - T0).count();
+      box_merge(tb, mb);
+      box_merge(bb, mb);
+    }
+    uint32_t n_shapes = (uint32_t)(gr.shapes.size() + gr.mtris.size());
     {
       RtNode& n = f.nodes[idx];
       n.xform = xf;
@@ -822,6 +1217,18 @@ struct Flattener {
   }
 
   void run() {
+    {
+      size_t n_shapes = w.shapes.size(), n_nodes = w.groups.size();
+      for (const HGroup& g : w.groups) n_shapes += g.mtris.size();
+      f.shapes.reserve(n_shapes);
+      f.nodes.reserve(n_nodes);
+      true_box.reserve(n_nodes);
+      size_t n_tris = w.tris.size();
+      for (const auto& m : w.meshes) n_tris += m->tris.size();
+      f.tri_geom.reserve(n_tris);
+      f.tri_normals.reserve(n_tris);
+      runs.reserve(n_nodes);
+    }
     tables();
     for (int c : w.world_csgs) {
       uint32_t first = (uint32_t)f.csg_nodes.size();
@@ -829,10 +1236,12 @@ struct Flattener {
       emit_csg(c, &lo, &hi);
       f.csg_roots.push_back(RtCsgRoot{first, (uint32_t)f.csg_nodes.size() - first});
     }
+    auto TG = std::chrono::steady_clock::now();
     for (int g : w.world_groups) {
       Box b, t;
       emit_group(g, -1, &b, &t);
     }
+    if (std::getenv("RT_TIMING")) std::fprintf(stderr, "flatten: groups %.3f s (triangle loops %.3f, geometry runs %.3f)\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - TG).count(), t_loop, t_run);
     uint32_t loose0 = (uint32_t)f.shapes.size();
     for (uint32_t s : w.world_shapes) emit_shape(s, -1);
     for (auto& l : w.lights) f.lights.push_back(l.l);
@@ -1000,6 +1409,7 @@ int rth_shape_new(RtbWorld* w, int kind, const RtbXfOp* ops, int nops, const Rtb
       t.n3 = P3{params[15], params[16], params[17]};
     }
     w->tris.push_back(t);
+    w->tri_gid.push_back(w->tri_values.get(w->tris.back(), kind == RTB_SMOOTH_TRIANGLE));
     s.tri = (int)w->tris.size() - 1;
   } else if ((kind == RTB_CYLINDER || kind == RTB_CONE) && params && nparams >= 3) {
     s.mn = params[0];
@@ -1029,6 +1439,7 @@ int rth_group_set_transform(RtbWorld* w, int g, const RtbXfOp* ops, int nops) {
 int rth_group_add_shape(RtbWorld* w, int g, int shape) {
   if (g < 0 || g >= (int)w->groups.size() || shape < 0 || shape >= (int)w->shapes.size())
     return fail(w, "bad handle");
+  w->materialise(g);                             // a mesh group that also gets other shapes holds shapes only
   uint32_t s = w->clone_shape((uint32_t)shape);  // groups.rs:80-85: the group owns a copy
   w->shapes[s].parent = g;
   w->groups[g].shapes.push_back(s);
@@ -1045,48 +1456,148 @@ int rth_group_add_child(RtbWorld* w, int g, int child) {
 int rth_group_add_mesh(RtbWorld* w, int g, const RtbMaterial* material, const float* positions, int npositions,
                        const float* normals, int nnormals, const int32_t* vidx, const int32_t* nidx, int ntriangles) {
   if (g < 0 || g >= (int)w->groups.size()) return fail(w, "bad group handle");
-  int child = w->new_group();
-  RtbMaterial mat = material ? *material : default_material();
-  w->groups[child].shapes.reserve(ntriangles);
-  w->shapes.reserve(w->shapes.size() + ntriangles);
-  w->tris.reserve(w->tris.size() + ntriangles);
-  for (int t = 0; t < ntriangles; t++) {
-    HTri tr{};
-    P3* ps[3] = {&tr.p1, &tr.p2, &tr.p3};
-    for (int c = 0; c < 3; c++) {
-      int vi = vidx[3 * t + c];
-      if (vi < 0 || vi >= npositions) return fail(w, "mesh position index out of range");
-      *ps[c] = P3{positions[3 * vi], positions[3 * vi + 1], positions[3 * vi + 2]};
+  if (npositions < 0 || nnormals < 0 || ntriangles < 0) return fail(w, "negative mesh size");
+  const bool has_n = normals && nidx;
+  // the same arrays handed in again (scene.rs:593-599 re-parses the file for every `obj:` use): one HMesh
+  auto fnv = [](uint64_t h, const void* p, size_t n) {
+    const uint64_t* q = static_cast<const uint64_t*>(p);
+    for (size_t i = 0; i + 8 <= n; i += 8) {
+      uint64_t v;
+      std::memcpy(&v, reinterpret_cast<const char*>(q) + i, 8);
+      h = (h ^ v) * 0x100000001B3ull;
+      h ^= h >> 31;
     }
-    tr.e1 = sub3(tr.p2, tr.p1);
-    tr.e2 = sub3(tr.p3, tr.p1);
-    bool smooth = normals && nidx;
-    if (smooth) {
-      P3* ns[3] = {&tr.n1, &tr.n2, &tr.n3};
-      for (int c = 0; c < 3; c++) {
-        int ni = nidx[3 * t + c];
-        if (ni < 0) {
-          smooth = false;
-          break;
-        }
-        if (ni >= nnormals) return fail(w, "mesh normal index out of range");
-        *ns[c] = P3{normals[3 * ni], normals[3 * ni + 1], normals[3 * ni + 2]};
-      }
-    }
-    if (!smooth) {
-      tr.n1 = normalize3(cross3(tr.e2, tr.e1));
-      tr.n2 = tr.n3 = P3{0.f, 0.f, 0.f};
-    }
-    w->tris.push_back(tr);
-    HShape s;
-    s.kind = smooth ? RTB_SMOOTH_TRIANGLE : RTB_TRIANGLE;
-    s.mat = mat;
-    s.tri = (int)w->tris.size() - 1;
-    s.parent = child;
-    s.psb = box_transform(w->local_bounds(s), s.xf);
-    w->shapes.push_back(s);
-    w->groups[child].shapes.push_back((uint32_t)w->shapes.size() - 1);
+    const unsigned char* c = static_cast<const unsigned char*>(p);
+    for (size_t i = n & ~(size_t)7; i < n; i++) h = (h ^ c[i]) * 0x100000001B3ull;
+    return h;
+  };
+  uint64_t h = 1469598103934665603ull ^ (uint64_t)ntriangles ^ ((uint64_t)npositions << 32);
+  h = fnv(h, positions, (size_t)npositions * 12);
+  h = fnv(h, vidx, (size_t)ntriangles * 12);
+  if (has_n) {
+    h = fnv(h, normals, (size_t)nnormals * 12);
+    h = fnv(h, nidx, (size_t)ntriangles * 12);
   }
+  const bool timing = std::getenv("RT_TIMING") != nullptr;
+  auto t_prev = std::chrono::steady_clock::now();
+  auto stage = [&](const char* what) {
+    if (!timing) return;
+    auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "group_add_mesh: %-24s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+    t_prev = now;
+  };
+  stage("hash inputs");
+  int mesh = -1;
+  for (size_t k = 0; k < w->meshes.size() && mesh < 0; k++) {
+    const HMesh& m = *w->meshes[k];
+    if (m.hash == h && m.in_pos.size() == (size_t)npositions * 3 && m.in_vidx.size() == (size_t)ntriangles * 3 &&
+        m.in_nrm.size() == (has_n ? (size_t)nnormals * 3 : 0) && m.in_nidx.size() == (has_n ? (size_t)ntriangles * 3 : 0) &&
+        std::memcmp(m.in_pos.data(), positions, m.in_pos.size() * 4) == 0 &&
+        std::memcmp(m.in_vidx.data(), vidx, m.in_vidx.size() * 4) == 0 &&
+        (!has_n || (std::memcmp(m.in_nrm.data(), normals, m.in_nrm.size() * 4) == 0 &&
+                    std::memcmp(m.in_nidx.data(), nidx, m.in_nidx.size() * 4) == 0)))
+      mesh = (int)k;
+  }
+  if (mesh < 0) {
+    std::unique_ptr<HMesh> mp(new HMesh());
+    HMesh& m = *mp;
+    m.hash = h;
+    m.in_pos.assign(positions, positions + (size_t)npositions * 3);
+    m.in_vidx.assign(vidx, vidx + (size_t)ntriangles * 3);
+    if (has_n) {
+      m.in_nrm.assign(normals, normals + (size_t)nnormals * 3);
+      m.in_nidx.assign(nidx, nidx + (size_t)ntriangles * 3);
+    }
+    stage("copy inputs");
+    m.tris.resize(ntriangles);
+    m.smooth.resize(ntriangles);
+    m.box.resize(ntriangles);
+    m.gid.resize(ntriangles);
+    const M4 ident = m4_identity();
+    for (int t = 0; t < ntriangles * 3; t++)
+      if (vidx[t] < 0 || vidx[t] >= npositions) return fail(w, "mesh position index out of range");
+    if (has_n)
+      for (int t = 0; t < ntriangles * 3; t++)
+        if (nidx[t] >= nnormals) return fail(w, "mesh normal index out of range");
+    const int n_threads = ntriangles >= 65536 ? (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency())) : 1;
+    auto work = [&](int t_begin, int t_end) {
+    for (int t = t_begin; t < t_end; t++) {
+      HTri tr{};
+      P3* ps[3] = {&tr.p1, &tr.p2, &tr.p3};
+      for (int c = 0; c < 3; c++) {
+        int vi = vidx[3 * t + c];
+        *ps[c] = P3{positions[3 * vi], positions[3 * vi + 1], positions[3 * vi + 2]};
+      }
+      tr.e1 = sub3(tr.p2, tr.p1);  // Triangle::new (triangle.rs:32-48)
+      tr.e2 = sub3(tr.p3, tr.p1);
+      bool smooth = has_n;
+      if (smooth) {
+        P3* ns[3] = {&tr.n1, &tr.n2, &tr.n3};
+        for (int c = 0; c < 3; c++) {
+          int ni = nidx[3 * t + c];
+          if (ni < 0) {
+            smooth = false;
+            break;
+          }
+          *ns[c] = P3{normals[3 * ni], normals[3 * ni + 1], normals[3 * ni + 2]};
+        }
+      }
+      if (!smooth) {
+        tr.n1 = normalize3(cross3(tr.e2, tr.e1));
+        tr.n2 = tr.n3 = P3{0.f, 0.f, 0.f};
+      }
+      m.tris[t] = tr;
+      m.smooth[t] = smooth ? RTB_SMOOTH_TRIANGLE : RTB_TRIANGLE;
+      Box lb;  // triangle.rs:117-123, then shapes.rs:318-320 with the identity transform
+      box_add(lb, tr.p1);
+      box_add(lb, tr.p2);
+      box_add(lb, tr.p3);
+      m.box[t] = box_transform(lb, ident);
+    }
+    };
+    if (n_threads == 1) {
+      work(0, ntriangles);
+    } else {
+      std::vector<std::thread> pool;
+      const int per = (ntriangles + n_threads - 1) / n_threads;
+      for (int k = 0; k < n_threads; k++) pool.emplace_back(work, std::min(ntriangles, k * per), std::min(ntriangles, (k + 1) * per));
+      for (auto& th : pool) th.join();
+    }
+    stage("triangles and boxes");
+    w->tri_values.reserve((size_t)ntriangles);
+    {
+      std::vector<uint64_t> hs(ntriangles);
+      std::vector<uint8_t> nans(ntriangles);
+      auto hash_work = [&](int b, int e) {
+        for (int t = b; t < e; t++) {
+          bool nan;
+          hs[t] = TriValueTable::value_hash(m.tris[t], m.smooth[t] == RTB_SMOOTH_TRIANGLE, &nan);
+          nans[t] = nan;
+        }
+      };
+      if (n_threads == 1) {
+        hash_work(0, ntriangles);
+      } else {
+        std::vector<std::thread> pool;
+        const int per = (ntriangles + n_threads - 1) / n_threads;
+        for (int k = 0; k < n_threads; k++) pool.emplace_back(hash_work, std::min(ntriangles, k * per), std::min(ntriangles, (k + 1) * per));
+        for (auto& th : pool) th.join();
+      }
+      for (int t = 0; t < ntriangles; t++)
+        m.gid[t] = w->tri_values.get_hashed(m.tris[t], m.smooth[t] == RTB_SMOOTH_TRIANGLE, hs[t], nans[t] != 0);
+    }
+    stage("geometry value classes");
+    w->meshes.push_back(std::move(mp));
+    mesh = (int)w->meshes.size() - 1;
+  }
+  int child = w->new_group();
+  HGroup& cg = w->groups[child];
+  cg.mesh = mesh;
+  cg.mmat = material ? *material : default_material();
+  if (cg.mmat.pattern >= (int)w->patterns.size()) return fail(w, "bad pattern handle");
+  cg.mtris.resize(ntriangles);
+  for (int t = 0; t < ntriangles; t++) cg.mtris[t] = (uint32_t)t;
+  cg.fresh_mesh = true;
   w->attach_child(g, child);
   w->touch();
   return child;

@@ -102,6 +102,7 @@ struct TreeBuilder {
   std::vector<Tri> tris;
   float lmax = 0.f, amax = 0.f;
   int depth_seen = 0;
+  int par_levels = 0;  // top levels of the tree whose halves are built by separate threads (2^par_levels threads)
   float blo[3] = {INFINITY, INFINITY, INFINITY}, bhi[3] = {-INFINITY, -INFINITY, -INFINITY};
 
   bool add(uint32_t tri, uint32_t shape, uint32_t owner) {
@@ -159,9 +160,18 @@ struct TreeBuilder {
     }
     return l;
   }
-  // child reference for [b,e): (index, count) and its box
-  void build(uint32_t b, uint32_t e, int depth, uint32_t* ref, uint32_t* count, float* lo, float* hi) {
-    depth_seen = std::max(depth_seen, depth);
+  struct Out {
+    std::vector<Node> nodes;
+    std::vector<Tri> tris;
+    int depth_seen = 0;
+  };
+  // child reference for [b,e): (index, count) and its box.  Nodes and leaf triangles go to `out` (indices local to it).
+  // par > 0: the two halves of a large range are built by two threads into outputs of their own and appended, left
+  // then right -- the same pre-order layout as the serial build.
+  void build(uint32_t b, uint32_t e, int depth, uint32_t* ref, uint32_t* count, float* lo, float* hi, Out& out, int par) {
+    std::vector<Node>& nodes = out.nodes;
+    std::vector<Tri>& tris = out.tris;
+    out.depth_seen = std::max(out.depth_seen, depth);
     for (int a = 0; a < 3; a++) lo[a] = INFINITY, hi[a] = -INFINITY;
     for (uint32_t i = b; i < e; i++)
       for (int a = 0; a < 3; a++) {
@@ -290,8 +300,28 @@ struct TreeBuilder {
         }
       }
     }
-    build(b, mid, depth + 1, &nd.left, &nd.lcount, nd.lmin, nd.lmax);
-    build(mid, e, depth + 1, &nd.right, &nd.rcount, nd.rmin, nd.rmax);
+    if (par > 0 && n >= 32768) {
+      Out L, R;
+      std::thread th([&]() { build(b, mid, depth + 1, &nd.left, &nd.lcount, nd.lmin, nd.lmax, L, par - 1); });
+      build(mid, e, depth + 1, &nd.right, &nd.rcount, nd.rmin, nd.rmax, R, par - 1);
+      th.join();
+      auto append = [&](Out& sub, uint32_t* cref, uint32_t ccount) {
+        const uint32_t noff = (uint32_t)nodes.size(), toff = (uint32_t)tris.size();
+        for (Node q : sub.nodes) {
+          q.left += q.lcount ? toff : noff;
+          q.right += q.rcount ? toff : noff;
+          nodes.push_back(q);
+        }
+        tris.insert(tris.end(), sub.tris.begin(), sub.tris.end());
+        *cref += ccount ? toff : noff;
+        out.depth_seen = std::max(out.depth_seen, sub.depth_seen);
+      };
+      append(L, &nd.left, nd.lcount);
+      append(R, &nd.right, nd.rcount);
+    } else {
+      build(b, mid, depth + 1, &nd.left, &nd.lcount, nd.lmin, nd.lmax, out, 0);
+      build(mid, e, depth + 1, &nd.right, &nd.rcount, nd.rmin, nd.rmax, out, 0);
+    }
     nodes[me] = nd;
   }
 
@@ -299,13 +329,15 @@ struct TreeBuilder {
   bool finish() {
     uint32_t n = (uint32_t)items.size();
     if (n < kMinTris) return false;
-    nodes.clear();
-    tris.clear();
-    tris.reserve(n);
-    nodes.emplace_back();  // header
+    Out out;
+    out.tris.reserve(n);
+    out.nodes.emplace_back();  // header
     uint32_t ref, count;
     float lo[3], hi[3];
-    build(0, n, 1, &ref, &count, lo, hi);
+    build(0, n, 1, &ref, &count, lo, hi, out, par_levels);
+    nodes.swap(out.nodes);
+    tris.swap(out.tris);
+    depth_seen = out.depth_seen;
     if (count != 0 || ref != 1 || depth_seen > kMaxDepth) return false;
     Node& h = nodes[0];
     std::memset(&h, 0, sizeof(h));
@@ -371,6 +403,28 @@ inline Result build(const RtScene* s) {
       for (uint32_t k = 0; k < n.n_shapes; k++) f(n.first_tri + k, n.first_shape + k, i);
     }
   };
+  // canonical triangle ids: the smallest index with the same 48 bytes of geometry, so that instances are recognised
+  // whether the host shares one copy of the triangles between them (this repo's flattener) or repeats them (a host
+  // that flattens the reference's duplicated World as it is)
+  std::vector<uint32_t> canon(s->n_tris);
+  {
+    size_t cap = 16;
+    while (cap < (size_t)s->n_tris * 2 + 16) cap <<= 1;
+    std::vector<uint32_t> slots(cap, kNone);
+    for (uint32_t t = 0; t < s->n_tris; t++) {
+      uint64_t h = 1469598103934665603ull;
+      uint64_t w[6];
+      std::memcpy(w, &s->tri_geom[t], 48);
+      for (uint64_t x : w) {
+        h = (h ^ x) * 0x100000001B3ull;
+        h ^= h >> 29;
+      }
+      size_t i = h & (cap - 1);
+      while (slots[i] != kNone && std::memcmp(&s->tri_geom[slots[i]], &s->tri_geom[t], 48) != 0) i = (i + 1) & (cap - 1);
+      if (slots[i] == kNone) slots[i] = t;
+      canon[t] = slots[i];
+    }
+  }
   std::vector<Inst> inst(roots.size());
   for (size_t j = 0; j < roots.size(); j++) {
     Inst& I = inst[j];
@@ -378,33 +432,32 @@ inline Result build(const RtScene* s) {
     I.shape_base = 0xFFFFFFFFu;
     for_items(roots[j], [&](uint32_t, uint32_t shape, uint32_t) { I.shape_base = std::min(I.shape_base, shape), I.n_items++; });
     uint64_t h = 1469598103934665603ull;
-    auto mix = [&](const void* p, size_t n) {
-      const unsigned char* c = static_cast<const unsigned char*>(p);
-      for (size_t q = 0; q < n; q++) h = (h ^ c[q]) * 1099511628211ull;
-    };
     for_items(roots[j], [&](uint32_t tri, uint32_t shape, uint32_t owner) {
-      uint32_t rel[3] = {shape - I.shape_base, owner - roots[j], s->shapes[shape].kind_flags};
-      mix(&s->tri_geom[tri], sizeof(RtTriGeom));
-      mix(rel, sizeof(rel));
+      const uint64_t a = ((uint64_t)canon[tri] << 32) | (shape - I.shape_base);
+      const uint64_t b = ((uint64_t)(owner - roots[j]) << 32) | s->shapes[shape].kind_flags;
+      h = (h ^ a) * 0x100000001B3ull;
+      h ^= h >> 29;
+      h = (h ^ b) * 0x100000001B3ull;
+      h ^= h >> 29;
     });
     I.hash = h;
   }
   auto same_items = [&](size_t j1, size_t j2) {  // full comparison behind a hash match
     if (inst[j1].n_items != inst[j2].n_items) return false;
-    std::vector<uint32_t> t1, t2;
+    std::vector<uint32_t> t1;
+    t1.reserve((size_t)inst[j1].n_items * 4);
     for_items(roots[j1], [&](uint32_t tri, uint32_t shape, uint32_t owner) {
-      t1.push_back(tri), t1.push_back(shape - inst[j1].shape_base), t1.push_back(owner - roots[j1]),
+      t1.push_back(canon[tri]), t1.push_back(shape - inst[j1].shape_base), t1.push_back(owner - roots[j1]),
           t1.push_back(s->shapes[shape].kind_flags);
     });
+    size_t q = 0;
+    bool same = true;
     for_items(roots[j2], [&](uint32_t tri, uint32_t shape, uint32_t owner) {
-      t2.push_back(tri), t2.push_back(shape - inst[j2].shape_base), t2.push_back(owner - roots[j2]),
-          t2.push_back(s->shapes[shape].kind_flags);
+      same = same && t1[q] == canon[tri] && t1[q + 1] == shape - inst[j2].shape_base && t1[q + 2] == owner - roots[j2] &&
+             t1[q + 3] == s->shapes[shape].kind_flags;
+      q += 4;
     });
-    for (size_t q = 0; q < t1.size(); q += 4) {
-      if (t1[q + 1] != t2[q + 1] || t1[q + 2] != t2[q + 2] || t1[q + 3] != t2[q + 3]) return false;
-      if (std::memcmp(&s->tri_geom[t1[q]], &s->tri_geom[t2[q]], sizeof(RtTriGeom)) != 0) return false;
-    }
-    return true;
+    return same;
   };
   for (size_t j = 1; j < roots.size(); j++)
     for (size_t q = 0; q < j; q++)
@@ -431,6 +484,7 @@ inline Result build(const RtScene* s) {
       TreeBuilder tb;
       tb.geom = s->tri_geom;
       tb.shapes_ = s->shapes;
+      while (((size_t)todo.size() << tb.par_levels) < 16) tb.par_levels++;  // about 16 threads in all
       bool ok = true;
       for (uint32_t i = R; ok && i < s->nodes[R].skip; i++) {
         const RtNode& n = s->nodes[i];

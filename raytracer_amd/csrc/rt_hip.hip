@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -600,7 +601,17 @@ const char* rt_last_error(const RtContext* c) { return c ? c->error.c_str() : "n
 int rt_scene_create(RtContext* ctx, const RtScene* s, RtDeviceScene** out) {
   if (!ctx || !s || !out) return RT_E_ABI;
   *out = nullptr;
+  // RT_TIMING=1 in the environment: stage times of the scene set-up on stderr
+  const bool timing = std::getenv("RT_TIMING") != nullptr;
+  auto t_prev = std::chrono::steady_clock::now();
+  auto stage = [&](const char* what) {
+    if (!timing) return;
+    auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "rt_scene_create: %-28s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+    t_prev = now;
+  };
   int rc = validate_scene(ctx, s);
+  stage("validate");
   if (rc != RT_OK) return rc;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   RtDeviceScene* ds = new RtDeviceScene();
@@ -640,14 +651,25 @@ int rt_scene_create(RtContext* ctx, const RtScene* s, RtDeviceScene** out) {
     // duplicates in groups with different boxes a ray within rounding of one box's face may report the other id
     // (the id only: the shapes are equal, so is the colour).
     {
+      // only classes that occur more than once can have duplicates: count first (one pass), sort the few that remain
       std::vector<std::pair<uint64_t, uint32_t>> keyed;
+      std::vector<uint8_t> seen;  // per class: 1 = seen once, 2 = more than once
+      uint32_t max_class = 0;
+      for (uint32_t i = 0; i < s->n_shapes; i++)
+        if (shapes[i].vclass != RT_VCLASS_NEVER) max_class = std::max(max_class, shapes[i].vclass);
+      seen.assign((size_t)max_class + 1, 0);
       for (uint32_t i = 0; i < s->n_shapes; i++)
         if ((shapes[i].kind_flags & RT_SHAPE_KIND_MASK) >= RT_TRIANGLE) {
-          const int32_t par = shapes[i].parent;
-          const int64_t anchor = par >= 0 ? (int64_t)s->nodes[par].next_xf + 1 : 0;
           memcpy(&shapes[i].mn, &i, sizeof(uint32_t));
           // a triangle that holds a NaN equals no shape, itself included: it is nobody's duplicate
-          if (shapes[i].vclass != RT_VCLASS_NEVER) keyed.emplace_back(((uint64_t)shapes[i].vclass << 32) | (uint64_t)anchor, i);
+          if (shapes[i].vclass != RT_VCLASS_NEVER && seen[shapes[i].vclass] < 2) seen[shapes[i].vclass]++;
+        }
+      for (uint32_t i = 0; i < s->n_shapes; i++)
+        if ((shapes[i].kind_flags & RT_SHAPE_KIND_MASK) >= RT_TRIANGLE && shapes[i].vclass != RT_VCLASS_NEVER &&
+            seen[shapes[i].vclass] == 2) {
+          const int32_t par = shapes[i].parent;
+          const int64_t anchor = par >= 0 ? (int64_t)s->nodes[par].next_xf + 1 : 0;
+          keyed.emplace_back(((uint64_t)shapes[i].vclass << 32) | (uint64_t)anchor, i);
         }
       std::sort(keyed.begin(), keyed.end());
       for (size_t a = 0; a < keyed.size();) {
@@ -657,6 +679,7 @@ int rt_scene_create(RtContext* ctx, const RtScene* s, RtDeviceScene** out) {
         a = b;
       }
     }
+    stage("cull records, duplicate links");
     const float* dc = nullptr;
     UP(d.shapes, shapes.data(), shapes.size())
     UP(dc, cull.data(), cull.size())
@@ -668,12 +691,15 @@ int rt_scene_create(RtContext* ctx, const RtScene* s, RtDeviceScene** out) {
       return fail(ctx, RT_E_DEVICE, std::string("scene upload: ") + hipGetErrorString(e));
     }
   }
+  stage("upload shapes");
   UP(tg, s->tri_geom, (size_t)s->n_tris)
   UP(tn, s->tri_normals, (size_t)s->n_tris)
+  stage("upload triangles");
   {
     // the library's own acceleration data: auxiliary BVHs under triangle-heavy groups (rt_accel.h);
     // the device copy of a node carries its aux root in the slot of n_children (unused on the device)
     rtaccel::Result acc = rtaccel::build(s);
+    stage("auxiliary trees");
     std::vector<RtNode> nodes(s->nodes, s->nodes + s->n_nodes);
     // groups that hold a shape with shadow() == false somewhere below them (any-shadow search, rt_device.h)
     for (uint32_t i = 0; i < s->n_shapes; i++)
@@ -697,7 +723,9 @@ int rt_scene_create(RtContext* ctx, const RtScene* s, RtDeviceScene** out) {
       }
     }
     // cull records of transformed groups: the record index rides in the idrun slot (0 for every transformed node)
+    stage("node flags");
     rtaccel::NodeCull nc = rtaccel::build_node_cull(s);
+    stage("subtree cull records");
     for (uint32_t i = 0; i < s->n_nodes; i++)
       if (nc.rec_of[i] != rtaccel::kNone) {
         nodes[i].idrun = nc.rec_of[i];
@@ -722,6 +750,7 @@ int rt_scene_create(RtContext* ctx, const RtScene* s, RtDeviceScene** out) {
       return fail(ctx, RT_E_DEVICE, std::string("scene upload: ") + hipGetErrorString(e));
     }
   }
+  stage("upload nodes and trees");
   UP(d.csg_nodes, s->csg_nodes, (size_t)s->n_csg_nodes)
   UP(d.csg_roots, s->csg_roots, (size_t)s->n_csg_roots)
   UP(d.materials, s->materials, (size_t)s->n_materials)
