@@ -1,0 +1,126 @@
+"""Host set-up with instanced meshes: a mesh handed to group_add_mesh several times is kept once,
+divided once per threshold and flattened with shared triangle data -- and the result is what the generic path (every
+triangle a shape of its own, partitioned by Group::divide as restated from groups.rs:198-299) produces."""
+import numpy as np
+
+from conftest import small_dragons
+from raytracer_amd import abi, builder as B, host
+
+
+def _mesh(rng, n):
+    gx, gz = np.meshgrid(np.linspace(-2, 2, n), np.linspace(-2, 2, n))
+    pos = np.stack([gx, 0.4 * np.sin(3 * gx) * np.cos(2 * gz) + rng.uniform(-0.05, 0.05, gx.shape), gz], axis=-1).reshape(-1, 3)
+    idx = np.arange(n * n).reshape(n, n)
+    a, b, c, d = idx[:-1, :-1].ravel(), idx[1:, :-1].ravel(), idx[:-1, 1:].ravel(), idx[1:, 1:].ravel()
+    tris = np.concatenate([np.stack([a, b, c], 1), np.stack([b, d, c], 1)])
+    tris = np.concatenate([tris, tris[rng.choice(len(tris), 4)]]).astype(np.int32)  # a few triangles listed twice
+    nrm = np.stack([-np.cos(3 * gx), np.ones_like(gx), np.sin(2 * gz)], -1).reshape(-1, 3)
+    return pos.astype(np.float32), nrm.astype(np.float32), tris
+
+
+def _relabel(a):
+    seen, out = {}, np.empty(len(a), dtype=np.int64)
+    for i, x in enumerate(a):
+        out[i] = seen.setdefault(int(x), len(seen))
+    return out
+
+
+def _world(pos, nrm, tris, smooth, thresholds, generic):
+    w = host.new_world(0)
+    for k, th in enumerate(thresholds):
+        g = w.group([("rotate-y", 0.3 * k), ("translate", 3.0 * k, 0, 0)])
+        mat = B.Material(color=(1.0, 0.1 * k, 0.2))
+        if generic:  # the reference's own way: one shape per triangle (obj.rs:24-36), an OBJ group under the root
+            child = w.group(())
+            for t in tris:
+                p = pos[t]
+                if smooth:
+                    s = w.shape("smooth-triangle", (), mat, params=[*p[0], *p[1], *p[2], *nrm[t[0]], *nrm[t[1]], *nrm[t[2]]])
+                else:
+                    s = w.shape("triangle", (), mat, params=[*p[0], *p[1], *p[2]])
+                w.group_add_shape(child, s)
+            w.group_add_child(g, child)
+        else:
+            w.group_add_mesh(g, mat, pos, nrm if smooth else None, tris, tris if smooth else None)
+        w.group_divide(g, th)
+        w.add_group(g)
+    w.add_point_light((-5, 10, -5), (1, 1, 1))
+    return abi.scene_arrays(w.flatten())
+
+
+def test_mesh_path_flattens_like_one_shape_per_triangle():
+    rng = np.random.RandomState(4)
+    pos, nrm, tris = _mesh(rng, 12)
+    for smooth in (False, True):
+        for thresholds in ([5, 5, 5], [1, 40, 1], [10 ** 6, 3]):
+            a = _world(pos, nrm, tris, smooth, thresholds, generic=False)
+            b = _world(pos, nrm, tris, smooth, thresholds, generic=True)
+            assert len(a["nodes"]) == len(b["nodes"]) and len(a["shapes"]) == len(b["shapes"])
+            for f in ("bmin", "bmax", "xform", "flags", "first_shape", "n_shapes", "skip", "parent", "next_xf", "idrun", "n_children"):
+                assert a["nodes"][f].tobytes() == b["nodes"][f].tobytes(), f
+            for f in ("kind_flags", "xform", "material", "parent", "mn", "mx"):
+                assert a["shapes"][f].tobytes() == b["shapes"][f].tobytes(), f
+            # value classes: the same equalities (the ids themselves are first-seen numbers)
+            assert np.array_equal(_relabel(a["shapes"]["vclass"]), _relabel(b["shapes"]["vclass"]))
+            # triangle data: shared between instances on the mesh path, the same values shape by shape
+            assert np.array_equal(a["tri_geom"][a["shapes"]["prim"]], b["tri_geom"][b["shapes"]["prim"]])
+            assert np.array_equal(a["tri_normals"][a["shapes"]["prim"]], b["tri_normals"][b["shapes"]["prim"]])
+            # a node's own triangles are a contiguous run from first_tri in both
+            for arr in (a, b):
+                n = arr["nodes"]
+                tri_nodes = np.flatnonzero((n["flags"] & abi.RT_NODE_ALL_TRIS) != 0)
+                for i in tri_nodes:
+                    f0, k = int(n["first_shape"][i]), int(n["n_shapes"][i])
+                    assert np.array_equal(arr["shapes"]["prim"][f0:f0 + k], int(n["first_tri"][i]) + np.arange(k))
+            # one copy per distinct way of dividing the mesh at most (equal runs of different divisions are shared too)
+            assert len(tris) <= len(a["tri_geom"]) <= len(tris) * len(set(thresholds))
+            assert len(b["tri_geom"]) == len(tris) * len(thresholds)
+
+
+def test_six_dragons_hold_one_copy_of_the_triangles():
+    scene = small_dragons(24, 16)
+    fs = scene.build(host.new_world(0)).flatten()
+    arr = abi.scene_arrays(fs)
+    n_mesh = 2 * 24 * 16
+    assert fs.n_tris == n_mesh and len(arr["tri_geom"]) == n_mesh
+    tri_shapes = arr["shapes"][(arr["shapes"]["kind_flags"] & abi.RT_SHAPE_KIND_MASK) >= 5]
+    assert len(tri_shapes) == 6 * n_mesh
+    assert np.array_equal(np.sort(tri_shapes["prim"].reshape(6, n_mesh), axis=1), np.tile(np.arange(n_mesh), (6, 1)))
+    # six different materials: no value class is shared between instances, each instance has its mesh's classes
+    vc = tri_shapes["vclass"].reshape(6, n_mesh)
+    assert len(np.unique(vc)) == 6 * len(np.unique(vc[0]))
+    # and the library recognises the six subtrees as one tree (shared auxiliary BVH)
+    acc = abi.accel_arrays(host.hip_lib(), fs)
+    roots = acc["root_of"][acc["root_of"] != 0xFFFFFFFF]
+    tops = {int(acc["nodes"][r]["lmax"][2].view(np.uint32)) for r in roots}
+    assert len(roots) == 6 and len(tops) == 1
+
+
+def test_a_mesh_group_that_gets_another_shape_holds_shapes():
+    """Adding a shape to the group group_add_mesh returned turns its triangles into ordinary shapes first (insertion
+    order kept: the mesh came first), so nothing depends on the fast path."""
+    rng = np.random.RandomState(2)
+    pos, nrm, tris = _mesh(rng, 6)
+    out = []
+    for generic in (False, True):
+        w = host.new_world(0)
+        g = w.group([("scale", 2, 2, 2)])
+        mat = B.Material(color=(0.3, 0.6, 0.9))
+        if generic:
+            child = w.group(())
+            for t in tris:
+                p = pos[t]
+                w.group_add_shape(child, w.shape("triangle", (), mat, params=[*p[0], *p[1], *p[2]]))
+            w.group_add_child(g, child)
+        else:
+            child = w.group_add_mesh(g, mat, pos, None, tris, None)
+        w.group_add_shape(child, w.shape("sphere", [("translate", 0, 1, 0)]))
+        w.group_divide(g, 4)
+        w.add_group(g)
+        out.append(abi.scene_arrays(w.flatten()))
+    a, b = out
+    assert a["nodes"].tobytes() == b["nodes"].tobytes()
+    for f in ("kind_flags", "xform", "material", "parent", "prim"):
+        assert a["shapes"][f].tobytes() == b["shapes"][f].tobytes(), f
+    assert np.array_equal(_relabel(a["shapes"]["vclass"]), _relabel(b["shapes"]["vclass"]))
+    assert a["tri_geom"].tobytes() == b["tri_geom"].tobytes()
