@@ -220,6 +220,7 @@ def main():
 
     # the same frame through rt_render: host buffers out (pageable memory), the PCIe-inclusive figure (never `value`)
     host_frame_ms = None
+    host_frame_u8_ms = None
     eighths_ms = None
     if world == 1 and rank == 0:
         hbuf = np.empty((cam.vsize, cam.hsize, 3), dtype=np.float32)
@@ -230,6 +231,15 @@ def main():
             check(lib.rt_render(ctx, dscene, C.byref(rcam), C.byref(fopts), hbuf.ctypes.data, None, None), "rt_render")
             hms.append((time.perf_counter() - th) * 1e3)
         host_frame_ms = round(min(hms[1:]), 3)
+        # and through rt_render_u8: quantised on the device (canvas.rs:73-75), a quarter of the bytes over PCIe
+        ubuf = np.empty((cam.vsize, cam.hsize, 3), dtype=np.uint8)
+        ums = []
+        for _ in range(4):
+            th = time.perf_counter()
+            check(lib.rt_render_u8(ctx, dscene, C.byref(rcam), C.byref(fopts), abi.RT_DITHER_NONE, ubuf.ctypes.data, None,
+                                   None), "rt_render_u8")
+            ums.append((time.perf_counter() - th) * 1e3)
+        host_frame_u8_ms = round(min(ums[1:]), 3)
         # strong-scaling preview: kernel time of each eighth of the frame (what each of 8 GPUs would render)
         eighths_ms = []
         for p in range(8):
@@ -268,7 +278,7 @@ def main():
                        "rays_traced": int(total_rays),
                        # what the reference would cast: it re-traces secondary rays once per light
                        "rays_reference": int(ref_rays),
-                       "frame_ms": round(ms_per_step, 3), "host_frame_ms": host_frame_ms,
+                       "frame_ms": round(ms_per_step, 3), "host_frame_ms": host_frame_ms, "host_frame_u8_ms": host_frame_u8_ms,
                        "eighths_kernel_ms": eighths_ms, "scene_setup_s": round(setup_s, 2)},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }

@@ -274,6 +274,25 @@ uint32_t rt_part_rows(const RtCamera*, const RtRenderOptions*);
 int rt_render(RtContext*, const RtDeviceScene*, const RtCamera*, const RtRenderOptions*, float* out_rgb,
               RtAux* aux /* host pointers, may be NULL */, RtStats* stats /* may be NULL */);
 
+/* What Scene::render does with the canvas after Camera::render (src/scene.rs:215-224), on the device: ordered
+ * dithering (Canvas::apply_dithering, src/canvas.rs:37-55, Bayer matrix of src/effects/dithering.rs:12-37) and the
+ * 8-bit quantisation of Canvas::to_ppm (src/canvas.rs:73-75): u8 = round(clamp(c, 0, 1) * 255), half away from zero.
+ * RT_DITHER_BAYER2..16 are `apply_dithering::<N>(false)` (black or white), RT_DITHER_BAYER_COLOR is
+ * `apply_dithering::<4>(true)` (the matrix value is added to the colour), as src/scene.rs:216-221 maps the CLI flag. */
+enum { RT_DITHER_NONE = 0, RT_DITHER_BAYER2 = 1, RT_DITHER_BAYER4 = 2, RT_DITHER_BAYER8 = 3, RT_DITHER_BAYER16 = 4,
+       RT_DITHER_BAYER_COLOR = 5 };
+
+/* Camera::render + apply_dithering + the quantisation of to_ppm: writes rows*hsize*3 u8 (row-major RGB) to HOST
+ * memory -- a quarter of the bytes rt_render moves. */
+int rt_render_u8(RtContext*, const RtDeviceScene*, const RtCamera*, const RtRenderOptions*, uint32_t dither,
+                 uint8_t* out_u8, RtAux* aux /* host pointers, may be NULL */, RtStats* stats /* may be NULL */);
+
+/* The same post-processing for a frame (or part: opts gives the interleave, so that a part dithers exactly like the
+ * rows of the whole frame) already in device memory: d_rgb rows*hsize*3 f32 -> d_out_u8 rows*hsize*3 u8, asynchronous
+ * on `stream` (NULL = the context's stream).  Multi-GPU hosts gather the u8 rows instead of the f32 ones. */
+int rt_canvas_to_u8_device(RtContext*, const RtCamera*, const RtRenderOptions*, uint32_t dither, const float* d_rgb,
+                           uint8_t* d_out_u8, void* stream);
+
 /* Same, but out_rgb / aux are DEVICE pointers on the context's GPU and nothing is copied back;
  * `stream` is a hipStream_t (NULL = the context's own stream, NOT the legacy null stream: a caller whose
  * other work is on the null stream, e.g. torch's default stream, must create a stream, pass it here and

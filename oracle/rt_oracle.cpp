@@ -1815,6 +1815,79 @@ int orc_color_at(RtbWorld* w, const RtbRenderOptions* opts, const float* origins
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------
+// What Scene::render does with the canvas after Camera::render (scene.rs:215-224): ordered dithering
+// (canvas.rs:37-55 over the Bayer matrix of effects/dithering.rs:12-37), then the 8-bit quantisation of to_ppm
+// (canvas.rs:73-75, the same rule as tuples.rs:367-377).  Restated for the device's u8 output path.
+// ---------------------------------------------------------------------------------------
+// effects/dithering.rs:12-37: out[i * n + j] = bayer[i][j]
+int orc_bayer_matrix(int n, float* out) {
+  if (n < 2 || (n & (n - 1)) != 0 || n > 64) return -1;  // is_pow2 (:39-41)
+  std::vector<float> res((size_t)n * n, 0.f);
+  auto at = [&](int i, int j) -> float& { return res[(size_t)i * n + j]; };
+  for (int i = 0; i < n; i++) at(i, i) = 1.f;  // Matrix::identity()
+  at(0, 0) = 0.f;
+  at(0, 1) = 2.f;
+  at(1, 0) = 3.f;
+  at(1, 1) = 1.f;
+  int size = 2;
+  int log2n = 0;
+  while ((1 << log2n) < n) log2n++;
+  for (int step = 1; step < log2n; step++) {
+    for (int j = 0; j < size; j++)
+      for (int i = 0; i < size; i++) at(i, j) *= powf(2.f, 2.f);
+    for (int j = 0; j < size; j++)
+      for (int i = 0; i < size; i++) {
+        at(size + i, j) = at(i, j) + 3.f;
+        at(i, size + j) = at(i, j) + 2.f;
+        at(size + i, size + j) = at(i, j) + 1.f;
+      }
+    size *= 2;
+  }
+  const float k = 1.f / (float)(n * n);  // (1. / res.size().0.pow(2) as f32) * res
+  for (float& v : res) v = k * v;
+  std::memcpy(out, res.data(), res.size() * sizeof(float));
+  return 0;
+}
+static inline uint8_t quantise(float c) {  // (0_f32.max(c).min(1.) * 255.).round() as u8
+  float lo = std::isnan(c) ? 0.f : (c > 0.f ? c : 0.f);  // f32::max returns the other operand for a NaN
+  float cl = lo < 1.f ? lo : 1.f;
+  float r = roundf(cl * 255.f);  // half away from zero
+  return (uint8_t)r;
+}
+// dither: 0 none, 1..4 Bayer2/4/8/16 (black or white), 5 BayerColor (N = 4, added to the colour) -- scene.rs:216-221.
+// rgb: w*h*3 f32 row-major (the canvas of Camera::render); out: w*h*3 u8.  Row r of the buffer is image row rows[r]
+// (NULL: r itself), so that a part of an interleaved frame dithers like the whole frame does.
+int orc_canvas_to_u8(const float* rgb, uint32_t w, uint32_t h, int dither, const uint32_t* rows, uint8_t* out) {
+  const int ns[6] = {0, 2, 4, 8, 16, 4};
+  if (dither < 0 || dither > 5) return -1;
+  const int n = ns[dither];
+  std::vector<float> bayer;
+  if (n) {
+    bayer.resize((size_t)n * n);
+    orc_bayer_matrix(n, bayer.data());
+  }
+  for (uint32_t r = 0; r < h; r++) {
+    const uint32_t y = rows ? rows[r] : r;
+    for (uint32_t x = 0; x < w; x++) {
+      const float* p = rgb + ((size_t)r * w + x) * 3;
+      float c[3] = {p[0], p[1], p[2]};
+      if (n) {
+        const float d = bayer[(size_t)(x % n) * n + (y % n)];  // bayer[x % N][y % N] (canvas.rs:41)
+        if (dither == 5) {
+          for (float& v : c) v = v + d;  // pixel + Color::new(d, d, d)
+        } else {
+          const bool black = c[0] < d || c[1] < d || c[2] < d;
+          c[0] = c[1] = c[2] = black ? 0.f : 1.f;
+        }
+      }
+      uint8_t* o = out + ((size_t)r * w + x) * 3;
+      for (int k = 0; k < 3; k++) o[k] = quantise(c[k]);
+    }
+  }
+  return 0;
+}
+
 int orc_ray_for_pixel(RtbWorld* w, const RtbCamera* cam, uint32_t px, uint32_t py, float out[6], float* pixel_size) {
   Camera c;
   if (!make_camera(cam, &c)) return fail(w, "camera transform is not invertible");

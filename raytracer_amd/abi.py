@@ -13,6 +13,7 @@ RT_VCLASS_NEVER = 0xFFFFFFFF
 RT_NODE_ALL_TRIS, RT_NODE_PRUNABLE = 1, 2
 RT_CSG_LEFT_IS_SHAPE, RT_CSG_RIGHT_IS_SHAPE = 1, 2
 RT_JITTER_CONST, RT_JITTER_COUNTER = 0, 1
+RT_DITHER_NONE, RT_DITHER_BAYER2, RT_DITHER_BAYER4, RT_DITHER_BAYER8, RT_DITHER_BAYER16, RT_DITHER_BAYER_COLOR = range(6)
 RT_RENDER_NO_PRUNE, RT_RENDER_COUNT_WORK, RT_RENDER_NO_ACCEL, RT_RENDER_WORK_MAP = 1, 2, 4, 8
 
 # numpy dtypes of the device records (must match the C structs byte for byte)
@@ -98,7 +99,7 @@ AUX_TRI = np.dtype([("p1", "<f4", 3), ("shape", "<u4"), ("e1", "<f4", 3), ("owne
 assert AUX_NODE.itemsize == 80 and AUX_TRI.itemsize == 48
 
 EXPORTS = ["rt_accel_build", "rt_accel_free", "rt_abi_version", "rt_context_create", "rt_context_destroy", "rt_last_error", "rt_scene_create",
-           "rt_scene_destroy", "rt_part_rows", "rt_render", "rt_render_device", "rt_check", "rt_color_at", "rt_color_at_static"]
+           "rt_scene_destroy", "rt_part_rows", "rt_render", "rt_render_u8", "rt_canvas_to_u8_device", "rt_render_device", "rt_check", "rt_color_at", "rt_color_at_static"]
 
 
 def declare(lib: C.CDLL) -> None:
@@ -115,6 +116,11 @@ def declare(lib: C.CDLL) -> None:
     lib.rt_render.restype = C.c_int
     lib.rt_render.argtypes = [P, P, C.POINTER(RtCamera), C.POINTER(RtRenderOptions), P, C.POINTER(RtAux),
                               C.POINTER(RtStats)]
+    lib.rt_render_u8.restype = C.c_int
+    lib.rt_render_u8.argtypes = [P, P, C.POINTER(RtCamera), C.POINTER(RtRenderOptions), C.c_uint32, P, C.POINTER(RtAux),
+                                 C.POINTER(RtStats)]
+    lib.rt_canvas_to_u8_device.restype = C.c_int
+    lib.rt_canvas_to_u8_device.argtypes = [P, C.POINTER(RtCamera), C.POINTER(RtRenderOptions), C.c_uint32, P, P, P]
     lib.rt_render_device.restype = C.c_int
     lib.rt_render_device.argtypes = [P, P, C.POINTER(RtCamera), C.POINTER(RtRenderOptions), P, C.POINTER(RtAux), P,
                                      C.POINTER(RtStats)]

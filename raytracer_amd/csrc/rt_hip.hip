@@ -293,6 +293,71 @@ __global__ __launch_bounds__(RT_BLOCK) void k_color_at_direct(Scene sc, RenderPa
   flush_counters(cn, counters, sc.sticky);
 }
 
+// What the reference does with the canvas after Camera::render (scene.rs:215-224), on the device: ordered dithering
+// (Canvas::apply_dithering, canvas.rs:37-55) over the Bayer matrix of effects/dithering.rs:12-37, then the 8-bit
+// quantisation of Canvas::to_ppm (canvas.rs:73-75).  A 4K frame leaves the GPU as 25 MB instead of 100.
+// The matrix entry bayer[i][j] of the reference's recursion (each step: old * 4, then +3 / +2 / +1 for the quadrants
+// [size+i][j] / [i][size+j] / [size+i][size+j]) is, bit by bit, sum over levels l of q(bit l of i, bit l of j) * 4^(L-1-l)
+// with q(0,0) = 0, q(0,1) = 2, q(1,0) = 3, q(1,1) = 1, times 1/N^2: all exact in f32.
+__device__ __forceinline__ float bayer_value(uint32_t i, uint32_t j, uint32_t levels) {
+  uint32_t v = 0;
+  for (uint32_t l = 0; l < levels; l++) {
+    const uint32_t ib = (i >> l) & 1u, jb = (j >> l) & 1u;
+    const uint32_t q = ib ? (jb ? 1u : 3u) : (jb ? 2u : 0u);
+    v |= q << (2u * (levels - 1u - l));
+  }
+  return (float)v * (1.0f / (float)(1u << (2u * levels)));
+}
+__device__ __forceinline__ uint32_t quantise_u8(float c) {  // (0_f32.max(c).min(1.) * 255.).round() as u8
+  const float lo = c > 0.f ? c : 0.f;  // NaN -> 0, as f32::max does
+  const float cl = lo < 1.f ? lo : 1.f;
+  return (uint32_t)roundf(cl * 255.f);  // half away from zero
+}
+__device__ __forceinline__ void post_pixel(float& r, float& g, float& b, uint32_t x, uint32_t y, uint32_t dither) {
+  if (dither == RT_DITHER_NONE) return;
+  const uint32_t levels = dither == RT_DITHER_BAYER_COLOR ? 2u : dither;  // Bayer2/4/8/16 = 1..4 levels; colour: N = 4
+  const uint32_t mask = (1u << levels) - 1u;
+  const float d = bayer_value(x & mask, y & mask, levels);  // bayer[x % N][y % N] (canvas.rs:41)
+  if (dither == RT_DITHER_BAYER_COLOR) {
+    r = r + d, g = g + d, b = b + d;
+  } else {
+    const bool black = r < d || g < d || b < d;
+    r = g = b = black ? 0.f : 1.f;
+  }
+}
+// four pixels per thread: three 16-B loads, three 4-B stores; `n` pixels in all, `hsize` per row
+__global__ __launch_bounds__(256) void k_canvas_to_u8(const float* __restrict__ rgb, uint8_t* __restrict__ out, uint64_t n,
+                                                      uint32_t hsize, PartInfo part, uint32_t dither) {
+  const uint64_t p0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4u;
+  if (p0 >= n) return;
+  float v[12];
+  const bool aligned = (((uintptr_t)rgb & 15u) | ((uintptr_t)out & 3u)) == 0u;
+  const uint32_t cnt = n - p0 >= 4u ? 4u : (uint32_t)(n - p0);
+  if (cnt == 4u && aligned) {
+    const float4* q = reinterpret_cast<const float4*>(rgb + 3u * p0);
+    const float4 a = q[0], b = q[1], c = q[2];
+    v[0] = a.x, v[1] = a.y, v[2] = a.z, v[3] = a.w, v[4] = b.x, v[5] = b.y, v[6] = b.z, v[7] = b.w;
+    v[8] = c.x, v[9] = c.y, v[10] = c.z, v[11] = c.w;
+  } else {
+    for (uint32_t k = 0; k < 12; k++) v[k] = k < 3u * cnt ? rgb[3u * p0 + k] : 0.f;
+  }
+  uint32_t bytes[12];
+  for (uint32_t k = 0; k < 4; k++) {
+    const uint64_t p = p0 + k;
+    const uint32_t x = (uint32_t)(p % hsize), ly = (uint32_t)(p / hsize);
+    const uint32_t y = (ly / part.tile_h) * (part.n_parts * part.tile_h) + part.part * part.tile_h + (ly % part.tile_h);
+    post_pixel(v[3 * k], v[3 * k + 1], v[3 * k + 2], x, y, dither);
+    for (uint32_t c = 0; c < 3; c++) bytes[3 * k + c] = quantise_u8(v[3 * k + c]);
+  }
+  if (cnt == 4u && aligned) {
+    uint32_t* o = reinterpret_cast<uint32_t*>(out + 3u * p0);
+    for (uint32_t wd = 0; wd < 3; wd++)
+      o[wd] = bytes[4 * wd] | (bytes[4 * wd + 1] << 8) | (bytes[4 * wd + 2] << 16) | (bytes[4 * wd + 3] << 24);
+  } else {
+    for (uint32_t k = 0; k < 3u * cnt; k++) out[3u * p0 + k] = (uint8_t)bytes[k];
+  }
+}
+
 }  // namespace
 
 // =========================================================================================
@@ -329,8 +394,8 @@ struct RtContext {
   unsigned char* static_scratch = nullptr;  // this device's copy of `scratch` (hipGetSymbolAddress), never the symbol's name
   uint32_t n_cus = 256;
   // frame buffers of rt_render, kept between calls (grow only)
-  void* d_frame[4] = {nullptr, nullptr, nullptr, nullptr};  // rgb, mask, object id, hit t
-  size_t frame_bytes[4] = {0, 0, 0, 0};
+  void* d_frame[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // rgb, mask, object id, hit t, 8-bit rgb
+  size_t frame_bytes[5] = {0, 0, 0, 0, 0};
   std::string error;
 };
 struct RtDeviceScene {
@@ -894,24 +959,47 @@ int rt_check(RtContext* ctx, void* stream_) {
   return take_sticky_overflow(ctx, ctx->stream);
 }
 
-// Host-memory entry point.  The frame buffers live in the context between calls; a full frame is rendered as up to
+static int launch_quantize(RtContext* ctx, const float* d_rgb, uint8_t* d_out, uint64_t n_pixels, uint32_t hsize,
+                           const PartInfo& part, uint32_t dither, hipStream_t stream) {
+  if (n_pixels == 0) return RT_OK;
+  const uint64_t threads = (n_pixels + 3u) / 4u;
+  hipLaunchKernelGGL(k_canvas_to_u8, dim3((uint32_t)((threads + 255u) / 256u)), dim3(256), 0, stream, d_rgb, d_out, n_pixels, hsize,
+                     part, dither);
+  HIP_TRY(ctx, hipGetLastError());
+  return RT_OK;
+}
+
+int rt_canvas_to_u8_device(RtContext* ctx, const RtCamera* cam, const RtRenderOptions* opts, uint32_t dither,
+                           const float* d_rgb, uint8_t* d_out_u8, void* stream_) {
+  if (!ctx || !cam || !d_rgb || !d_out_u8) return RT_E_ABI;
+  if (dither > RT_DITHER_BAYER_COLOR) return fail(ctx, RT_E_ABI, "unknown dither mode");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const PartInfo part = make_part(cam, opts);
+  if (part.part >= part.n_parts) return fail(ctx, RT_E_ABI, "part >= n_parts");
+  return launch_quantize(ctx, d_rgb, d_out_u8, (uint64_t)part.rows * cam->hsize, cam->hsize, part, dither,
+                         stream_ ? (hipStream_t)stream_ : ctx->stream);
+}
+
+// Host-memory entry points.  The frame buffers live in the context between calls; a full frame is rendered as up to
 // RT_MAX_BANDS bands of rows, each copied back on a second stream while the next one renders (the copy of a 4K
-// f32 frame takes longer than its kernel).
-int rt_render(RtContext* ctx, const RtDeviceScene* ds, const RtCamera* cam, const RtRenderOptions* opts,
-              float* out_rgb, RtAux* aux, RtStats* stats) {
-  if (!ctx || !ds || !cam || !out_rgb) return RT_E_ABI;
+// f32 frame takes longer than its kernel).  out_u8 != NULL: each band is dithered / quantised on the device and the
+// 8-bit rows are what is copied (a quarter of the bytes).
+static int render_host(RtContext* ctx, const RtDeviceScene* ds, const RtCamera* cam, const RtRenderOptions* opts,
+                       float* out_rgb, uint8_t* out_u8, uint32_t dither, RtAux* aux, RtStats* stats) {
+  if (!ctx || !ds || !cam || (!out_rgb && !out_u8)) return RT_E_ABI;
   if (ds->owner != ctx) return fail(ctx, RT_E_ABI, "scene belongs to another context");
   if (cam->hsize == 0 || cam->vsize == 0) return fail(ctx, RT_E_ABI, "empty camera");
+  if (dither > RT_DITHER_BAYER_COLOR) return fail(ctx, RT_E_ABI, "unknown dither mode");
   auto t0 = std::chrono::steady_clock::now();
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const PartInfo whole = make_part(cam, opts);
   if (whole.part >= whole.n_parts) return fail(ctx, RT_E_ABI, "part >= n_parts");
   const size_t npix = (size_t)whole.rows * cam->hsize;
-  const size_t elem[4] = {3 * sizeof(float), 1, sizeof(int32_t), sizeof(float)};
-  void* host[4] = {out_rgb, aux ? (void*)aux->hit_mask : nullptr, aux ? (void*)aux->object_id : nullptr,
-                   aux ? (void*)aux->hit_t : nullptr};
-  for (int k = 0; k < 4; k++) {
-    if (!host[k]) continue;
+  const size_t elem[5] = {3 * sizeof(float), 1, sizeof(int32_t), sizeof(float), 3};
+  void* host[5] = {out_rgb, aux ? (void*)aux->hit_mask : nullptr, aux ? (void*)aux->object_id : nullptr,
+                   aux ? (void*)aux->hit_t : nullptr, out_u8};
+  for (int k = 0; k < 5; k++) {
+    if (!host[k] && !(k == 0 && out_u8)) continue;  // the f32 frame is rendered even when only its 8-bit form is wanted
     size_t need = (npix ? npix : 1) * elem[k];
     if (ctx->frame_bytes[k] < need) {
       if (ctx->d_frame[k]) (void)hipFree(ctx->d_frame[k]);
@@ -946,6 +1034,9 @@ int rt_render(RtContext* ctx, const RtDeviceScene* ds, const RtCamera* cam, cons
              host[3] ? (float*)ctx->d_frame[3] + p0 : nullptr};
     int rc = launch_part(ctx, sc, cam, rp, bands[b], (float*)ctx->d_frame[0] + 3 * p0, aux ? &da : nullptr, ctx->stream,
                          d_blocks + (size_t)b * RT_N_COUNTERS);
+    if (rc == RT_OK && out_u8)
+      rc = launch_quantize(ctx, (float*)ctx->d_frame[0] + 3 * p0, (uint8_t*)ctx->d_frame[4] + 3 * p0,
+                           (uint64_t)bands[b].rows * cam->hsize, cam->hsize, bands[b], dither, ctx->stream);
     if (rc != RT_OK) {
       (void)hipStreamSynchronize(ctx->stream);
       return rc;
@@ -961,7 +1052,7 @@ int rt_render(RtContext* ctx, const RtDeviceScene* ds, const RtCamera* cam, cons
     const size_t p0 = row0 * cam->hsize;
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev_band[b], 0));
     const size_t n = (size_t)bands[b].rows * cam->hsize;
-    for (int k = 0; k < 4; k++)
+    for (int k = 0; k < 5; k++)
       if (host[k] && n)
         HIP_TRY(ctx, hipMemcpyAsync((char*)host[k] + p0 * elem[k], (char*)ctx->d_frame[k] + p0 * elem[k], n * elem[k],
                                     hipMemcpyDeviceToHost, ctx->copy_stream));
@@ -975,6 +1066,18 @@ int rt_render(RtContext* ctx, const RtDeviceScene* ds, const RtCamera* cam, cons
   if (rc != RT_OK) return rc;
   if (stats) *stats = local;
   return take_sticky_overflow(ctx, ctx->stream);
+}
+
+int rt_render(RtContext* ctx, const RtDeviceScene* ds, const RtCamera* cam, const RtRenderOptions* opts,
+              float* out_rgb, RtAux* aux, RtStats* stats) {
+  if (!out_rgb) return RT_E_ABI;
+  return render_host(ctx, ds, cam, opts, out_rgb, nullptr, RT_DITHER_NONE, aux, stats);
+}
+
+int rt_render_u8(RtContext* ctx, const RtDeviceScene* ds, const RtCamera* cam, const RtRenderOptions* opts, uint32_t dither,
+                 uint8_t* out_u8, RtAux* aux, RtStats* stats) {
+  if (!out_u8) return RT_E_ABI;
+  return render_host(ctx, ds, cam, opts, nullptr, out_u8, dither, aux, stats);
 }
 
 namespace {

@@ -51,6 +51,8 @@ class CanvasPipeline:
     """Frames in flight: the all-gather of frame k runs beside the render of frame k+1.
 
     Two sets of buffers (this rank's rows, the gathered blocks, the assembled canvas), no allocation per frame.
+    ``dtype=torch.uint8`` exchanges the 8-bit rows that rt_canvas_to_u8_device makes of a part (a quarter of the bytes:
+    3.1 MB per GPU instead of 12.4 MB at 4K over 8 GPUs).
     Per frame: render into ``next_local()``, then ``submit()``, which starts that frame's all-gather without
     waiting for it and returns the assembled canvas of the frame before (None for the first); ``finish()`` returns
     the last one.  A returned canvas stays valid until the second ``submit()`` after it.  On GPUs the collective

@@ -101,3 +101,39 @@ def test_canvas_pipeline_gloo(tmp_path, world, tile_h, size):
     port = 29950 + (os.getpid() % 300) + world
     mp.spawn(_pipeline_worker, args=(world, port, fp, tile_h, op), nprocs=world, join=True)
     assert np.load(op)[0] == 1
+
+
+def _u8_worker(rank, world, port, full_path, tile_h, dither, out_path):
+    from test_kat_canvas import to_u8
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        full = np.load(full_path)
+        vsize, hsize = full.shape[:2]
+        mine = tiles.part_rows(vsize, tile_h, world, rank)
+        pipe = tiles.CanvasPipeline(vsize, hsize, tile_h, torch.device("cpu"), dtype=torch.uint8)
+        local = pipe.next_local()
+        # what rt_canvas_to_u8_device makes of this rank's f32 rows: dithered by their row in the whole image
+        local[: len(mine)] = torch.from_numpy(to_u8(full[mine], dither, mine))
+        pipe.submit()
+        canvas = pipe.finish()
+        ok = canvas.dtype == torch.uint8 and torch.equal(canvas, torch.from_numpy(to_u8(full, dither)))
+        flag = torch.tensor([1 if ok else 0])
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if rank == 0:
+            np.save(out_path, np.array([int(flag.item())]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,tile_h,dither", [(2, 8, 0), (3, 2, 5), (2, 2, 3)])
+def test_u8_rows_gather_to_the_quantised_frame(tmp_path, world, tile_h, dither):
+    """The 8-bit exchange: every rank quantises / dithers its own rows, the all-gather moves a quarter of
+    the bytes, and the assembled canvas is the whole frame's apply_dithering + to_ppm bytes."""
+    rng = np.random.RandomState(8)
+    full = rng.uniform(-0.1, 1.1, size=(45, 52, 3)).astype(np.float32)
+    fp, op = str(tmp_path / "full.npy"), str(tmp_path / "ok.npy")
+    np.save(fp, full)
+    port = 30300 + (os.getpid() % 300) + world
+    mp.spawn(_u8_worker, args=(world, port, fp, tile_h, dither, op), nprocs=world, join=True)
+    assert np.load(op)[0] == 1
