@@ -61,6 +61,9 @@ def main():
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--tile-h", type=int, default=8)  # a multiple of 8 keeps every 8x8 wave tile inside one stripe
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    # only the timed loop and the roofline launches: no host-frame / eighths side measurements (tools/gpu_profile.sh uses
+    # it so that every dispatch of the render kernel in a profile is a full frame of the workload)
+    ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--force-gather", action="store_true")  # rehearse the N > 1 exchange step on one GPU (RCCL, world 1)
     ap.add_argument("--cpu-sample-pixels", type=int, default=900000)  # ~15 s of oracle work on 16 threads
     args = ap.parse_args()
@@ -222,7 +225,7 @@ def main():
     host_frame_ms = None
     host_frame_u8_ms = None
     eighths_ms = None
-    if world == 1 and rank == 0:
+    if world == 1 and rank == 0 and not args.no_extras:
         hbuf = np.empty((cam.vsize, cam.hsize, 3), dtype=np.float32)
         fopts = abi.RtRenderOptions(abi.RT_JITTER_COUNTER, 0.5, 1, 1, 1, 0, 0)
         hms = []
