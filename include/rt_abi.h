@@ -41,7 +41,7 @@ enum {
   RT_E_DEVICE = -2,  /* HIP error */
   RT_E_OOM = -3,     /* device allocation failed */
   RT_E_SCENE = -4,   /* scene violates a device limit (chain depth, csg depth, ...) */
-  RT_E_OVERFLOW = -5, /* a per-ray intersection list overflowed its capacity; image is invalid */
+  RT_E_OVERFLOW = -5, /* a per-ray intersection list overflowed (see rt_render_device); the image is invalid */
   RT_E_LIMIT = -6     /* an argument exceeds a fixed capacity of the entry point (rt_color_at_static) */
 };
 
@@ -303,17 +303,32 @@ int rt_canvas_to_u8_device(RtContext*, const RtCamera*, const RtRenderOptions*, 
  * up to 8 asynchronous launches may be in flight on any mix of streams; the 9th waits (stream-side) for the 1st.
  * The calls themselves are still made from one host thread at a time (a context is single-threaded).
  *
- * Overflow of a per-ray intersection list (RT_E_OVERFLOW): a synchronous call (stats != NULL, rt_render,
- * rt_color_at) returns it itself.  An asynchronous call cannot: its overflow is kept in the context and returned by the
- * NEXT synchronising call on that context, or by rt_check.  A caller that renders asynchronously must call rt_check
- * (or a synchronous entry point) before trusting the frames rendered since the last check. */
+ * Per-ray intersection lists.  The reference's list is unbounded (src/intersections.rs:66-73); the device keeps 96
+ * entries per ray for the n1/n2 walk of a refracted hit (src/intersections.rs:141-160) and, for a ray that passes them,
+ * continues in SIDE LISTS in device memory that belong to the context.  A context has none until one of its launches
+ * overflows; then it allocates them (512 entries per ray and resident lane, 1.6 GB on an MI355X) and a further
+ * overflow makes them four times as large, up to RT_SIDE_MAX entries (default 8192 = 26 GB; the environment variable
+ * RT_SIDE_MAX lowers or raises it).  While a context has side lists its launches run one after another and always
+ * through the persistent kernel.
+ *   - A synchronous call (stats != NULL, rt_render, rt_render_u8, rt_color_at) does this by itself: it grows the side
+ *     lists and runs again, and returns the right image.  RT_E_OVERFLOW from it means a ray passed RT_SIDE_MAX entries
+ *     or the allocation failed.
+ *   - An asynchronous call (stats == NULL) cannot: its overflow is kept in the context and returned, once, by the NEXT
+ *     synchronising call on that context or by rt_check, which also grow the side lists so that rendering the lost
+ *     frames again succeeds.  A caller that renders asynchronously must call rt_check (or a synchronous entry point)
+ *     before trusting the frames rendered since the last check.
+ *   - rt_color_at_static may not allocate: it uses side lists the context already has and reports RT_E_OVERFLOW
+ *     otherwise.
+ * CSG trees need no such thing: rt_scene_create adds up the most intersections the leaves of a tree can give one ray
+ * and refuses (RT_E_SCENE) a tree that could pass the 32 entries of the device's csg list. */
 int rt_render_device(RtContext*, const RtDeviceScene*, const RtCamera*, const RtRenderOptions*, float* d_out_rgb,
                      RtAux* d_aux, void* stream, RtStats* stats);
 
 /* Synchronises `stream` (NULL: every stream of the context's GPU) and returns RT_E_OVERFLOW if any launch on this
- * context since the last synchronising call overflowed a per-ray list, RT_OK otherwise; clears the condition.
+ * context since the last synchronising call overflowed a per-ray list, RT_OK otherwise; clears the condition and gives
+ * the context (larger) side lists, so that the same frames rendered again come out right.
  * Where the reference's Camera::render would simply have returned (its Intersections list is unbounded,
- * src/intersections.rs:66-73), this is how the asynchronous path reports the device limit. */
+ * src/intersections.rs:66-73), this is how the asynchronous path reports that a frame must be rendered again. */
 int rt_check(RtContext*, void* stream);
 
 /* World::color_at(ray, remaining) (src/world.rs:91-99) and Intersections::hit()

@@ -121,6 +121,11 @@ struct Scene {
   uint32_t flags;  // RT_RENDER_*
   uint32_t props;  // RT_SCENE_* (derived by rt_scene_create)
   unsigned long long* sticky;  // the context's overflow word: launches add to it, synchronising calls read and clear it
+  // Side lists (rt_hip.hip grow_side): per-lane room in device memory for the rays whose n1/n2 intersection list passes
+  // RT_XS_CAP.  side_cap entries per lane and list (0: none); only the persistent kernels use it, a lane's
+  // region is found from its block and thread index.
+  char* side;
+  uint32_t side_cap;
 };
 
 // The scene tables are never written while a kernel runs.  Reading them through the constant address space tells the
@@ -406,7 +411,28 @@ enum { SINK_CLOSEST = 0, SINK_COLLECT = 1, SINK_CLOSEST_NOSHADOW = 2, SINK_ANY_S
 struct XsList {  // every intersection of a ray up to its hit: input of the n1/n2 walk
   float t[RT_XS_CAP];
   uint32_t s[RT_XS_CAP];
+  // entries RT_XS_CAP .. gcap-1 go to this lane's side list in device memory (gcap = 0: there is none); the
+  // reference's list is unbounded (intersections.rs:66-73)
+  float* gt;
+  uint32_t* gs;
+  int gcap;
 };
+#define RT_XS_OVERFLOWED 0x7FFFFFFF
+#ifndef RT_SIDE_XS
+#define RT_SIDE_XS 1
+#endif
+
+// A lane's side lists: [xs t | xs s | containers], side_cap entries each.
+enum { SIDE_XS_T = 0, SIDE_XS_S = 1, SIDE_CONTAINERS = 2, SIDE_LISTS = 3 };
+__device__ __forceinline__ char* side_list(const Scene& sc, int which) {
+  const size_t lane = (size_t)blockIdx.x * RT_BLOCK + threadIdx.x;
+  return sc.side + (lane * SIDE_LISTS + (size_t)which) * sc.side_cap * 4u;
+}
+__device__ __forceinline__ void xs_attach_side(const Scene& sc, XsList& xl) {
+  xl.gcap = (int)sc.side_cap;
+  xl.gt = sc.side_cap ? reinterpret_cast<float*>(side_list(sc, SIDE_XS_T)) : nullptr;
+  xl.gs = sc.side_cap ? reinterpret_cast<uint32_t*>(side_list(sc, SIDE_XS_S)) : nullptr;
+}
 // Eight registers: the modes never need their private state at the same time, so it shares fields, and the
 // per-intersection decisions (takes / wants / add) are written as selects over those fields rather than as
 // branches on the mode: lanes of a wave are in different modes, and every branch costs exec-mask bookkeeping in the
@@ -419,7 +445,7 @@ struct Sink {
   float t;
   int shape;
   float a, b;    // closest: (u, v) of the best hit
-  int c;         // collect: entries stored (> RT_XS_CAP: the list overflowed)
+  int c;         // collect: entries stored (RT_XS_OVERFLOWED: the list, side list included, overflowed)
   XsList* xs;    // collect: where the entries go
   float bound;
   int mode;
@@ -459,8 +485,9 @@ struct Sink {
   __device__ __forceinline__ float u() const { return a; }
   __device__ __forceinline__ float v() const { return b; }
   __device__ __forceinline__ bool found() const { return lim == -__builtin_inff(); }
-  __device__ __forceinline__ int count() const { return c > RT_XS_CAP ? RT_XS_CAP : c; }
-  __device__ __forceinline__ int overflow() const { return c > RT_XS_CAP ? 1 : 0; }
+  __device__ __forceinline__ int count() const { return c == RT_XS_OVERFLOWED ? 0 : c; }
+  __device__ __forceinline__ int overflow() const { return c == RT_XS_OVERFLOWED ? 1 : 0; }
+  __device__ __forceinline__ bool spilled() const { return c > RT_XS_CAP && c != RT_XS_OVERFLOWED; }
   // does this traversal look at a shape with these flags at all?
   __device__ __forceinline__ bool takes(uint32_t kind_flags) const {
     return (kind_flags & RT_SHAPE_SHADOW) ? mode != SINK_CLOSEST_NOSHADOW : mode != SINK_ANY_SHADOW;
@@ -477,8 +504,12 @@ struct Sink {
         xs->t[c] = tt;
         xs->s[c] = s;
         c++;
+      } else if (RT_SIDE_XS && c < xs->gcap) {  // past the per-lane list: the side list in device memory, if the context has one
+        xs->gt[c] = tt;
+        xs->gs[c] = s;
+        c++;
       } else {
-        c = RT_XS_CAP + 1;
+        c = RT_XS_OVERFLOWED;
       }
     } else {
       const bool any = mode == SINK_ANY_SHADOW;  // an occluder ends the search; a closest hit replaces the best
@@ -551,6 +582,11 @@ __device__ __forceinline__ void shape_intersect(const Scene& sc, uint32_t si, co
 // what the reference's nested stable sorts produce (DESIGN.md "CSG").
 // ---------------------------------------------------------------------------------------
 struct CsgList {
+  // RT_CSG_CAP entries are enough for every tree rt_scene_create accepts: it adds up the most intersections each leaf
+  // can have (validate_scene) and rejects a tree that could pass the capacity, so this list cannot overflow at run time
+  // (`overflow` stays as the check of that claim).  A spill path into the side lists was tried twice: as a second,
+  // inlined evaluation it cost the render kernel 28 more spilled registers and 5 % of the dragons frame; with the
+  // arrays behind pointers the direct kernel spilled thousands.
   float t[RT_CSG_CAP];
   uint32_t s[RT_CSG_CAP];
   int n;
@@ -571,6 +607,7 @@ __device__ __forceinline__ bool entry_less(float ta, uint32_t sa, float tb, uint
   return of_gt(tb, ta) || (of_eq(ta, tb) && sa < sb);
 }
 // Drop an entry that is == its successor (BTreeMap bulk build).
+template <int VARIANT = 0>
 __device__ inline int dedup_sorted(const Scene& sc, float* t, uint32_t* s, int lo, int hi) {
   int w = lo;
   for (int i = lo; i < hi; i++) {
@@ -581,6 +618,7 @@ __device__ inline int dedup_sorted(const Scene& sc, float* t, uint32_t* s, int l
   }
   return w;
 }
+template <int VARIANT = 0>
 __device__ inline void sort_entries(float* t, uint32_t* s, int lo, int hi) {
   for (int i = lo + 1; i < hi; i++) {
     float ti = t[i];
@@ -1485,13 +1523,13 @@ enum { ST_TRACE = 0, ST_NEXT_LIGHT, ST_LIGHTS_DONE, ST_SECONDARY, ST_NEXT_RAY, S
 
 // The n1/n2 walk of Computations::prepare (intersections.rs:141-160) over the sorted,
 // de-duplicated list of every intersection up to the hit.
-__device__ inline void refractive_indices(const Scene& sc, float* ts, uint32_t* ss, int count, float hit_t,
-                                          int hit_shape, float& n1, float& n2) {
-  sort_entries(ts, ss, 0, count);
-  int n = dedup_sorted(sc, ts, ss, 0, count);
+template <int VARIANT = 0>
+__device__ inline void refractive_indices(const Scene& sc, float* ts, uint32_t* ss, uint32_t* containers, int count,
+                                          float hit_t, int hit_shape, float& n1, float& n2) {
+  sort_entries<VARIANT>(ts, ss, 0, count);
+  int n = dedup_sorted<VARIANT>(sc, ts, ss, 0, count);
   n1 = 1.f;
   n2 = 1.f;
-  uint32_t containers[RT_XS_CAP];
   int nc = 0;
   uint32_t hit_vc = cst(sc.shapes)[hit_shape].vclass;
   for (int i = 0; i < n; i++) {
@@ -1513,6 +1551,22 @@ __device__ inline void refractive_indices(const Scene& sc, float* ts, uint32_t* 
       containers[nc++] = s;
     }
     if (is_hit && nc > 0) n2 = cst(sc.materials)[cst(sc.shapes)[containers[nc - 1]].material].refractive_index;
+  }
+}
+// The n1/n2 walk over what a COLLECT traversal left in `xl` (sink.c entries).  A list that went past RT_XS_CAP continues
+// in the lane's side list: its first RT_XS_CAP entries are copied there and the walk runs in device memory.
+__device__ inline void refractive_indices_of(const Scene& sc, XsList& xl, const Sink& sink, float hit_t, int hit_shape,
+                                             float& n1, float& n2) {
+  if (RT_SIDE_XS && sink.spilled()) {
+    for (int i = 0; i < RT_XS_CAP; i++) {
+      xl.gt[i] = xl.t[i];
+      xl.gs[i] = xl.s[i];
+    }
+    refractive_indices<1>(sc, xl.gt, xl.gs, reinterpret_cast<uint32_t*>(side_list(sc, SIDE_CONTAINERS)), sink.c, hit_t,
+                          hit_shape, n1, n2);
+  } else {
+    uint32_t containers[RT_XS_CAP];
+    refractive_indices<0>(sc, xl.t, xl.s, containers, sink.count(), hit_t, hit_shape, n1, n2);
   }
 }
 
@@ -1557,6 +1611,7 @@ __device__ inline void integrate(const Scene& sc, const RenderParams& rp, const 
                                  unsigned long long* queue, Counters& cn) {
   PendingRay stack[RT_MAX_RAY_STACK];
   XsList xl;
+  xs_attach_side(sc, xl);
   Park pk{threadIdx.x};
   int sp = 0;
   bool first = true;
@@ -1806,7 +1861,7 @@ __device__ inline void integrate(const Scene& sc, const RenderParams& rp, const 
       }
     } else {  // JOB_COLLECT
       cn.overflow += sink.overflow();
-      refractive_indices(sc, xl.t, xl.s, sink.count(), hit_t, hit_shape, n1, n2);
+      refractive_indices_of(sc, xl, sink, hit_t, hit_shape, n1, n2);
       st = ST_SECONDARY;
     }
 
@@ -2095,11 +2150,13 @@ __device__ __forceinline__ V3 color_at_direct(const Scene& sc, const RenderParam
     float n1 = 1.f, n2 = 1.f;
     if (want_refract && !(sc.props & RT_SCENE_RI_ALL_ONE)) {
       XsList xl;
+      xl.gcap = 0;  // no side lists in this kernel (simple_intersect)
       Sink cs;
       cs.init_collect(&xl, hit.t);
       simple_intersect<COUNT>(sc, ray, cs, cn);
       cn.overflow += cs.overflow();
-      refractive_indices(sc, xl.t, xl.s, cs.count(), hit.t, hit.shape, n1, n2);
+      uint32_t containers[RT_XS_CAP];
+      refractive_indices<0>(sc, xl.t, xl.s, containers, cs.count(), hit.t, hit.shape, n1, n2);
     }
     if (m_reflective > 0.f && m_transparency > 0.f) {  // Computations::schlick (intersections.rs:177-192)
       float cosv = dot(eyev, normalv);

@@ -396,6 +396,15 @@ struct RtContext {
   // frame buffers of rt_render, kept between calls (grow only)
   void* d_frame[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // rgb, mask, object id, hit t, 8-bit rgb
   size_t frame_bytes[5] = {0, 0, 0, 0, 0};
+  // Side lists: room in device memory for the n1/n2 intersection lists of rays that pass RT_XS_CAP entries (the
+  // reference's list is unbounded, intersections.rs:66-73).  None until a launch on this context overflows; then
+  // side_cap entries per list and resident lane (grow_side), four times as many after each further overflow.  While it
+  // exists every render goes through the persistent kernels (a lane there owns a fixed region of it), one launch at a
+  // time (ev_side orders them).
+  char* d_side = nullptr;
+  uint32_t side_cap = 0;
+  hipEvent_t ev_side = nullptr;
+  bool side_used = false;
   std::string error;
 };
 struct RtDeviceScene {
@@ -465,18 +474,27 @@ int validate_scene(RtContext* ctx, const RtScene* s) {
     const RtCsgRoot& root = s->csg_roots[r];
     if ((uint64_t)root.first + root.count > s->n_csg_nodes || root.count == 0) return bad("csg root range");
     int sp = 0;
+    // the most intersections one ray can have with the leaves of this tree (sphere, cube: 2; plane, triangle: 1;
+    // cylinder, cone: walls and caps, 4): the per-ray list of csg_eval (RT_CSG_CAP entries) must hold them all
+    uint32_t most = 0;
+    auto leaf_hits = [&](int32_t shape) {
+      const uint32_t kind = s->shapes[shape].kind_flags & RT_SHAPE_KIND_MASK;
+      return kind == RT_CYLINDER || kind == RT_CONE ? 4u : (kind == RT_SPHERE || kind == RT_CUBE ? 2u : 1u);
+    };
     for (uint32_t k = root.first; k < root.first + root.count; k++) {
       const RtCsgNode& n = s->csg_nodes[k];
       if (n.op > RT_CSG_DIFFERENCE) return bad("csg op");
       int nseg = 0;
       if (n.flags & RT_CSG_LEFT_IS_SHAPE) {
         if (n.left < 0 || (uint32_t)n.left >= s->n_shapes) return bad("csg left shape");
+        most += leaf_hits(n.left);
       } else {
         nseg++;
         if (n.left_lo > n.left_hi || n.left_hi > s->n_shapes) return bad("csg left leaf range");
       }
       if (n.flags & RT_CSG_RIGHT_IS_SHAPE) {
         if (n.right < 0 || (uint32_t)n.right >= s->n_shapes) return bad("csg right shape");
+        most += leaf_hits(n.right);
       } else {
         nseg++;
       }
@@ -485,6 +503,10 @@ int validate_scene(RtContext* ctx, const RtScene* s) {
       if (sp > RT_CSG_DEPTH) return bad("csg tree deeper than RT_CSG_DEPTH");
     }
     if (sp != 1) return bad("csg root does not reduce to one list");
+    if (most > RT_CSG_CAP)
+      return fail(ctx, RT_E_SCENE, "invalid scene: csg tree " + std::to_string(r) + " can give one ray " + std::to_string(most) +
+                                       " intersections, more than RT_CSG_CAP (" + std::to_string(RT_CSG_CAP) +
+                                       "); rebuild the library with a larger -DRT_CSG_CAP");
   }
   for (uint32_t i = 0; i < s->n_materials; i++)
     if (s->materials[i].pattern >= (int32_t)s->n_patterns || s->materials[i].pattern < -1) return bad("material pattern");
@@ -584,19 +606,92 @@ int ring_release(RtContext* ctx, hipStream_t stream, unsigned slot) {
   ctx->ring_used[slot] = true;
   return RT_OK;
 }
-// After `stream` has been synchronised: did any launch since the last check overflow a per-ray list?  Reads and clears
-// the context's sticky word, so an overflow in an asynchronous call (no stats) is reported by the next call that
-// synchronises, never lost.
-int take_sticky_overflow(RtContext* ctx, hipStream_t stream) {
+// After `stream` has been synchronised: the number of list overflows of every launch on this context since the last
+// check (the context's sticky word), which is cleared.  An overflow in an asynchronous call (no stats) is therefore
+// reported by the next call that synchronises, never lost.
+int take_sticky(RtContext* ctx, hipStream_t stream, unsigned long long* v) {
+  *v = 0;
+  HIP_TRY(ctx, hipMemcpyAsync(v, ctx->d_sticky, sizeof(*v), hipMemcpyDeviceToHost, stream));
+  HIP_TRY(ctx, hipStreamSynchronize(stream));
+  if (!*v) return RT_OK;
+  HIP_TRY(ctx, hipMemsetAsync(ctx->d_sticky, 0, sizeof(*v), stream));
+  HIP_TRY(ctx, hipStreamSynchronize(stream));
+  return RT_OK;
+}
+
+#ifndef RT_SIDE_FIRST
+#define RT_SIDE_FIRST 512u  // entries per list and lane of the first side-list allocation
+#endif
+#ifndef RT_SIDE_MAX
+#define RT_SIDE_MAX 8192u   // the largest: 12 B x 8192 x 262144 resident lanes = 26 GB of the 288
+#endif
+size_t side_lanes(const RtContext* ctx) { return (size_t)ctx->n_cus * RT_BLOCKS_PER_CU * RT_BLOCK; }
+// Gives the context side lists, or larger ones.  Synchronises the device: no launch may be using the old ones.
+int grow_side(RtContext* ctx) {
+  // RT_SIDE_MAX in the environment lowers (or raises) the limit: a host that would rather fail than give 26 GB away
+  uint32_t most = RT_SIDE_MAX;
+  if (const char* e = std::getenv("RT_SIDE_MAX")) most = (uint32_t)std::strtoul(e, nullptr, 10);
+  if (ctx->side_cap >= most)
+    return fail(ctx, RT_E_OVERFLOW, "a ray's intersection list passed " + std::to_string(std::max(most, (uint32_t)RT_XS_CAP)) +
+                                    " entries, the largest list this library keeps (RT_SIDE_MAX): the image is invalid");
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  const uint32_t cap = std::min(most, ctx->side_cap ? ctx->side_cap * 4u : RT_SIDE_FIRST);
+  if (ctx->d_side) (void)hipFree(ctx->d_side);
+  ctx->d_side = nullptr;
+  ctx->side_cap = 0;
+  if (!ctx->ev_side) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_side, hipEventDisableTiming));
+  const size_t bytes = side_lanes(ctx) * SIDE_LISTS * 4u * cap;  // 12 B per entry: t, shape, container
+  hipError_t e = hipMalloc((void**)&ctx->d_side, bytes);
+  if (e != hipSuccess) {
+    ctx->d_side = nullptr;
+    (void)hipGetLastError();
+    return fail(ctx, RT_E_OVERFLOW, "a ray's intersection list overflowed and the side lists (" + std::to_string(bytes >> 20) +
+                                    " MiB) could not be allocated: " + hipGetErrorString(e));
+  }
+  ctx->side_cap = cap;
+  ctx->side_used = false;
+  return RT_OK;
+}
+// What a synchronous call does about overflows once its stream is idle.  `own` = the overflows its own launch(es)
+// counted.  Its own overflow is cured by giving the context (larger) side lists and running the call again (*retry);
+// overflows left behind by EARLIER asynchronous calls cannot be cured here -- those frames are gone -- and are reported.
+int settle_overflow(RtContext* ctx, hipStream_t stream, unsigned long long own, bool may_grow, bool* retry,
+                    unsigned long long* earlier) {
+  *retry = false;
   unsigned long long v = 0;
-  HIP_TRY(ctx, hipMemcpyAsync(&v, ctx->d_sticky, sizeof(v), hipMemcpyDeviceToHost, stream));
-  HIP_TRY(ctx, hipStreamSynchronize(stream));
-  if (!v) return RT_OK;
-  HIP_TRY(ctx, hipMemsetAsync(ctx->d_sticky, 0, sizeof(v), stream));
-  HIP_TRY(ctx, hipStreamSynchronize(stream));
-  return fail(ctx, RT_E_OVERFLOW,
-              "per-ray intersection list overflow (" + std::to_string(v) + " rays) in this call or in an earlier asynchronous "
-              "call on this context: those images are invalid");
+  int rc = take_sticky(ctx, stream, &v);
+  if (rc != RT_OK) return rc;
+  if (v > own) *earlier += v - own;
+  if (own) {
+    if (!may_grow)
+      return fail(ctx, RT_E_OVERFLOW, "per-ray intersection list overflow (" + std::to_string(own) + " rays) and this entry "
+                                      "point may not allocate side lists: use rt_color_at");
+    rc = grow_side(ctx);
+    if (rc != RT_OK) return rc;
+    *retry = true;
+    return RT_OK;
+  }
+  if (*earlier)
+    return fail(ctx, RT_E_OVERFLOW, "per-ray intersection list overflow (" + std::to_string(*earlier) + " rays) in an earlier "
+                                    "asynchronous call on this context: those images are invalid (render them again: the "
+                                    "context now holds side lists of " + std::to_string(ctx->side_cap) + " entries)");
+  return RT_OK;
+}
+// Launches that use the side lists run one after another, whatever their streams.
+int side_enter(RtContext* ctx, hipStream_t stream) {
+  if (ctx->side_cap && ctx->side_used) HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->ev_side, 0));
+  return RT_OK;
+}
+int side_leave(RtContext* ctx, hipStream_t stream) {
+  if (ctx->side_cap) {
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_side, stream));
+    ctx->side_used = true;
+  }
+  return RT_OK;
+}
+void attach_side(const RtContext* ctx, Scene& sc) {
+  sc.side = ctx->d_side;
+  sc.side_cap = ctx->side_cap;
 }
 
 }  // namespace
@@ -648,6 +743,8 @@ void rt_context_destroy(RtContext* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->d_counters) (void)hipFree(c->d_counters);
+  if (c->d_side) (void)hipFree(c->d_side);
+  if (c->ev_side) (void)hipEventDestroy(c->ev_side);
   for (void* p : c->d_frame)
     if (p) (void)hipFree(p);
   for (hipEvent_t ev : c->ev_band)
@@ -882,8 +979,11 @@ static int launch_part(RtContext* ctx, const Scene& sc, const RtCamera* cam, con
                        float* d_out_rgb, const RtAux* d_aux, hipStream_t stream, unsigned long long* d_counters) {
   HIP_TRY(ctx, hipMemsetAsync(d_counters, 0, RT_N_COUNTERS * sizeof(unsigned long long), stream));
   if (part.rows == 0) return RT_OK;
+  int rc_side = side_enter(ctx, stream);
+  if (rc_side != RT_OK) return rc_side;
   // both integrators give the same bits; the direct one wins where an area light's sample loop dominates
-  const bool direct = sc.n_nodes == 0 && (sc.props & RT_SCENE_AREA_LIGHT);
+  // (a context with side lists renders through the persistent kernel only: its lanes own fixed regions of them)
+  const bool direct = sc.n_nodes == 0 && (sc.props & RT_SCENE_AREA_LIGHT) && !sc.side_cap;
   const bool count = (sc.flags & RT_RENDER_COUNT_WORK) != 0;
   PixelOut po{d_out_rgb, d_aux ? d_aux->hit_mask : nullptr, d_aux ? d_aux->object_id : nullptr,
               d_aux ? d_aux->hit_t : nullptr};
@@ -912,7 +1012,7 @@ static int launch_part(RtContext* ctx, const Scene& sc, const RtCamera* cam, con
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(RT_BLOCK), 0, stream, sc, *cam, rq, part, po, d_counters);
   }
   HIP_TRY(ctx, hipGetLastError());
-  return RT_OK;
+  return side_leave(ctx, stream);
 }
 
 int rt_render_device(RtContext* ctx, const RtDeviceScene* ds, const RtCamera* cam, const RtRenderOptions* opts,
@@ -929,24 +1029,28 @@ int rt_render_device(RtContext* ctx, const RtDeviceScene* ds, const RtCamera* ca
   sc.flags = opts ? opts->flags : 0;
   sc.sticky = ctx->d_sticky;
   RenderParams rp = make_params(opts);
-  unsigned slot = 0;
-  unsigned long long* block = nullptr;
-  int rc = ring_acquire(ctx, stream, &slot, &block);
-  if (rc != RT_OK) return rc;
-  if (stats) HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
-  rc = launch_part(ctx, sc, cam, rp, part, d_out_rgb, d_aux, stream, block);
-  if (rc != RT_OK) return rc;
-  if (stats) HIP_TRY(ctx, hipEventRecord(ctx->ev1, stream));
-  rc = ring_release(ctx, stream, slot);
-  if (rc != RT_OK) return rc;
-  if (stats) {
+  unsigned long long earlier = 0;
+  while (true) {
+    attach_side(ctx, sc);
+    unsigned slot = 0;
+    unsigned long long* block = nullptr;
+    int rc = ring_acquire(ctx, stream, &slot, &block);
+    if (rc != RT_OK) return rc;
+    if (stats) HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
+    rc = launch_part(ctx, sc, cam, rp, part, d_out_rgb, d_aux, stream, block);
+    if (rc != RT_OK) return rc;
+    if (stats) HIP_TRY(ctx, hipEventRecord(ctx->ev1, stream));
+    rc = ring_release(ctx, stream, slot);
+    if (rc != RT_OK) return rc;
+    if (!stats) return RT_OK;
     HIP_TRY(ctx, hipStreamSynchronize(stream));
     double total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     rc = read_stats(ctx, stream, stats, total, 1, block);
     if (rc != RT_OK) return rc;
-    return take_sticky_overflow(ctx, stream);
+    bool retry = false;
+    rc = settle_overflow(ctx, stream, stats->overflow, true, &retry, &earlier);
+    if (!retry) return rc;  // else: the context has (larger) side lists now; the same launch again
   }
-  return RT_OK;
 }
 
 int rt_check(RtContext* ctx, void* stream_) {
@@ -956,7 +1060,17 @@ int rt_check(RtContext* ctx, void* stream_) {
     HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)stream_));
   else
     HIP_TRY(ctx, hipDeviceSynchronize());  // every stream of this GPU, the context's own included
-  return take_sticky_overflow(ctx, ctx->stream);
+  unsigned long long v = 0;
+  int rc = take_sticky(ctx, ctx->stream, &v);
+  if (rc != RT_OK || !v) return rc;
+  // the frames are gone, but the next attempt need not fail: give the context (larger) side lists now
+  const int grown = grow_side(ctx);
+  return fail(ctx, RT_E_OVERFLOW,
+              "per-ray intersection list overflow (" + std::to_string(v) + " rays) in asynchronous calls on this context since "
+              "the last check: those images are invalid" +
+              (grown == RT_OK ? "; render them again, the context now holds side lists of " + std::to_string(ctx->side_cap) +
+                                    " entries per ray"
+                              : std::string("; ") + ctx->error));
 }
 
 static int launch_quantize(RtContext* ctx, const float* d_rgb, uint8_t* d_out, uint64_t n_pixels, uint32_t hsize,
@@ -1026,6 +1140,9 @@ static int render_host(RtContext* ctx, const RtDeviceScene* ds, const RtCamera* 
   sc.sticky = ctx->d_sticky;
   RenderParams rp = make_params(opts);
   unsigned long long* d_blocks = ctx->d_counters + (size_t)RT_RING * RT_N_COUNTERS;
+  unsigned long long earlier = 0;
+render_again:
+  attach_side(ctx, sc);
   HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   size_t row0 = 0;
   for (int b = 0; b < nb; b++) {
@@ -1065,7 +1182,10 @@ static int render_host(RtContext* ctx, const RtDeviceScene* ds, const RtCamera* 
   int rc = read_stats(ctx, ctx->stream, &local, total, nb, d_blocks);
   if (rc != RT_OK) return rc;
   if (stats) *stats = local;
-  return take_sticky_overflow(ctx, ctx->stream);
+  bool retry = false;
+  rc = settle_overflow(ctx, ctx->stream, local.overflow, true, &retry, &earlier);
+  if (retry) goto render_again;  // the context has (larger) side lists now: the same frame again
+  return rc;
 }
 
 int rt_render(RtContext* ctx, const RtDeviceScene* ds, const RtCamera* cam, const RtRenderOptions* opts,
@@ -1091,18 +1211,25 @@ struct RayBufs {
 int color_at_run(RtContext* ctx, const RtDeviceScene* ds, const RtRenderOptions* opts, const float* origins,
                  const float* directions, uint32_t n, uint32_t remaining, float* out_rgb, float* hit_t, int32_t* hit_id,
                  float* hit_uv, RtStats* stats_out, const RayBufs& b, unsigned long long* block,
-                 std::chrono::steady_clock::time_point t0) {
+                 std::chrono::steady_clock::time_point t0, bool may_grow) {
   const size_t n3 = (size_t)n * 3 * sizeof(float);
   HIP_TRY(ctx, hipMemcpyAsync(b.o, origins, n3, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(b.d, directions, n3, hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(ctx, hipMemsetAsync(block, 0, RT_N_COUNTERS * sizeof(unsigned long long), ctx->stream));
   Scene sc = ds->sc;
   sc.flags = opts ? opts->flags : 0;
   sc.sticky = ctx->d_sticky;
   RenderParams rp = make_params(opts);
+  unsigned long long earlier = 0;
+trace_again:
+  attach_side(ctx, sc);
+  HIP_TRY(ctx, hipMemsetAsync(block, 0, RT_N_COUNTERS * sizeof(unsigned long long), ctx->stream));
+  {
+    int rc_side = side_enter(ctx, ctx->stream);
+    if (rc_side != RT_OK) return rc_side;
+  }
   HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   RayOut ro{b.o, b.d, n, b.rgb, b.t, b.id, b.uv};
-  if (sc.n_nodes == 0) {
+  if (sc.n_nodes == 0 && !sc.side_cap) {  // (side lists belong to the lanes of the persistent kernel)
     hipLaunchKernelGGL(k_color_at_direct, dim3((n + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, ctx->stream, sc, rp, ro,
                        remaining, block);
   } else {
@@ -1114,6 +1241,10 @@ int color_at_run(RtContext* ctx, const RtDeviceScene* ds, const RtRenderOptions*
   }
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  {
+    int rc_side = side_leave(ctx, ctx->stream);
+    if (rc_side != RT_OK) return rc_side;
+  }
   if (out_rgb) HIP_TRY(ctx, hipMemcpyAsync(out_rgb, b.rgb, n3, hipMemcpyDeviceToHost, ctx->stream));
   if (hit_t) HIP_TRY(ctx, hipMemcpyAsync(hit_t, b.t, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
   if (hit_id) HIP_TRY(ctx, hipMemcpyAsync(hit_id, b.id, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -1124,7 +1255,10 @@ int color_at_run(RtContext* ctx, const RtDeviceScene* ds, const RtRenderOptions*
   int rc = read_stats(ctx, ctx->stream, &local, total, 1, block);
   if (rc != RT_OK) return rc;
   if (stats_out) *stats_out = local;
-  return take_sticky_overflow(ctx, ctx->stream);
+  bool retry = false;
+  rc = settle_overflow(ctx, ctx->stream, local.overflow, may_grow, &retry, &earlier);
+  if (retry) goto trace_again;
+  return rc;
 }
 }  // namespace
 
@@ -1157,7 +1291,7 @@ int rt_color_at(RtContext* ctx, const RtDeviceScene* ds, const RtRenderOptions* 
   unsigned long long* block = nullptr;
   int rc = ring_acquire(ctx, ctx->stream, &slot, &block);
   if (rc == RT_OK) {
-    rc = color_at_run(ctx, ds, opts, origins, directions, n, remaining, out_rgb, hit_t, hit_id, hit_uv, stats, b, block, t0);
+    rc = color_at_run(ctx, ds, opts, origins, directions, n, remaining, out_rgb, hit_t, hit_id, hit_uv, stats, b, block, t0, true);
     (void)ring_release(ctx, ctx->stream, slot);
   }
   (void)hipStreamSynchronize(ctx->stream);
@@ -1190,7 +1324,8 @@ int rt_color_at_static(RtContext* ctx, const RtDeviceScene* ds, const RtRenderOp
   unsigned long long* block = reinterpret_cast<unsigned long long*>(ctx->static_scratch + (size_t)RT_STATIC_WORDS * 4u);
   // the array keeps the last call's contents: the counter block is zeroed by color_at_run, every output word the
   // caller reads (entries 0..n) is written by the kernel
-  return color_at_run(ctx, ds, opts, origins, directions, n, remaining, out_rgb, hit_t, hit_id, hit_uv, stats, b, block, t0);
+  // (may_grow = false: growing the side lists would allocate)
+  return color_at_run(ctx, ds, opts, origins, directions, n, remaining, out_rgb, hit_t, hit_id, hit_uv, stats, b, block, t0, false);
 }
 
 }  // extern "C"

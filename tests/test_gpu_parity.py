@@ -457,32 +457,131 @@ class _GlassStack:
         return B.Camera(hsize, vsize, 0.8, (0, 0, 0.01 * (self.n - 20) + 0.005), (0, 0, 100.0), (0, 1, 0))
 
 
-def test_overflow_is_never_silent():
-    """A per-ray list longer than the device holds (RT_XS_CAP, include/rt_abi.h) must not yield an image that looks
-    valid.  A synchronous call returns RT_E_OVERFLOW itself; an asynchronous one (stats == NULL: bench loop, multi-GPU
-    callers) leaves it in the context, where the next synchronising call or rt_check finds it, once."""
+def test_overflow_is_never_silent(monkeypatch):
+    """The reference's intersection list is unbounded (intersections.rs:66-73); the device keeps RT_XS_CAP entries per
+    ray and, for a ray that passes them, continues in side lists in device memory that the context allocates when the
+    first such ray shows up.  A synchronous call does that by itself and runs again: it returns the right image.  An
+    asynchronous call (stats == NULL: bench loop, multi-GPU callers) cannot: its overflow stays in the context, where the
+    next synchronising call or rt_check finds it, once -- never an image that only looks valid."""
     import torch
-    raw = Raw(_GlassStack(140), (64, 48))
+    scene = _GlassStack(140)
+    want = scene.build(_oracle().new_world()).render(scene.camera(64, 48), B.RenderOptions(jitter_mode=B.JITTER_CONST), aux=True)
     opts = abi.RtRenderOptions(abi.RT_JITTER_CONST, 0.5, 0, 1, 1, 0, 0)
+
+    def same(rgb):
+        d = np.abs(to_u8(rgb).astype(int) - to_u8(want.rgb).astype(int)).max(axis=2)
+        return float((d <= 1).mean()) >= LSB_FRACTION
+
+    # asynchronous first: the overflow is reported by rt_check, once; the frame rendered again is right
+    raw = Raw(scene, (64, 48))
     out = torch.zeros((48, 64, 3), dtype=torch.float32, device=raw.dev)
     torch.cuda.synchronize()
-    st = abi.RtStats()
-    rc = raw.lib.rt_render_device(raw.ctx, raw.ds, C.byref(raw.rcam), C.byref(opts), out.data_ptr(), None, None, C.byref(st))
-    assert rc == abi.RT_E_OVERFLOW and st.overflow > 0 and b"overflow" in raw.lib.rt_last_error(raw.ctx)
+    rc = raw.lib.rt_render_device(raw.ctx, raw.ds, C.byref(raw.rcam), C.byref(opts), out.data_ptr(), None, None, None)
+    assert rc == abi.RT_OK  # nothing known yet
+    assert raw.lib.rt_check(raw.ctx, None) == abi.RT_E_OVERFLOW and b"overflow" in raw.lib.rt_last_error(raw.ctx)
     assert raw.lib.rt_check(raw.ctx, None) == abi.RT_OK  # reported once
-    rc = raw.lib.rt_render_device(raw.ctx, raw.ds, C.byref(raw.rcam), C.byref(opts), out.data_ptr(), None, None, None)
-    assert rc == abi.RT_OK  # asynchronous: nothing known yet
-    assert raw.lib.rt_check(raw.ctx, None) == abi.RT_E_OVERFLOW
+    for _ in range(2):  # two launches in flight on the side lists: ordered one after the other
+        rc = raw.lib.rt_render_device(raw.ctx, raw.ds, C.byref(raw.rcam), C.byref(opts), out.data_ptr(), None, None, None)
+        assert rc == abi.RT_OK
     assert raw.lib.rt_check(raw.ctx, None) == abi.RT_OK
-    # an earlier asynchronous overflow is reported by the next synchronous call, even one that is itself clean
-    rc = raw.lib.rt_render_device(raw.ctx, raw.ds, C.byref(raw.rcam), C.byref(opts), out.data_ptr(), None, None, None)
+    assert same(out.cpu().numpy())
+
+    # synchronous first, on a context of its own: the call allocates the side lists and renders again by itself
+    raw2 = Raw(scene, (64, 48))
+    rgb, ids, st = raw2.render(mode=abi.RT_JITTER_CONST)
+    assert st.overflow == 0 and same(rgb) and np.array_equal(ids, want.object_id)
+    host_out = np.zeros((48, 64, 3), dtype=np.float32)
+    raw3 = Raw(scene, (64, 48))
+    rc = raw3.lib.rt_render(raw3.ctx, raw3.ds, C.byref(raw3.rcam), C.byref(opts), host_out.ctypes.data, None, None)
+    assert rc == abi.RT_OK and same(host_out)
+
+    # an earlier asynchronous overflow is reported by the next synchronous call even though that call itself succeeds
+    raw4 = Raw(scene, (64, 48))
+    rc = raw4.lib.rt_render_device(raw4.ctx, raw4.ds, C.byref(raw4.rcam), C.byref(opts), out.data_ptr(), None, None, None)
     assert rc == abi.RT_OK
-    ok = Raw(_GlassStack(30), (64, 48))  # another context: unaffected
+    rc = raw4.lib.rt_render(raw4.ctx, raw4.ds, C.byref(raw4.rcam), C.byref(opts), host_out.ctypes.data, None, None)
+    assert rc == abi.RT_E_OVERFLOW and b"earlier" in raw4.lib.rt_last_error(raw4.ctx)
+    assert same(host_out)  # the synchronous call's own frame is the right one
+    assert raw4.lib.rt_check(raw4.ctx, None) == abi.RT_OK
+
+    # the entry point that may not allocate reports the overflow instead (rt_color_at_static); once rt_color_at has
+    # given the context its side lists, it works
+    raw5 = Raw(scene, (64, 48))
+    o = np.tile(np.array([[0.0, 0.0, 0.01 * 120 + 0.005]], dtype=np.float32), (64, 1))
+    d = np.tile(np.array([[0.0, 0.0, 1.0]], dtype=np.float32), (64, 1))
+
+    def static(n_expected_rc):
+        rgb = np.full((64, 3), np.nan, dtype=np.float32)
+        ids = np.full(64, -77, dtype=np.int32)
+        copts = abi.RtRenderOptions(abi.RT_JITTER_CONST, 0.5, 0, 1, 1, 0, 0)
+        rc = raw5.lib.rt_color_at_static(raw5.ctx, raw5.ds, C.byref(copts), o.ctypes.data, d.ctypes.data, 64, 4,
+                                         rgb.ctypes.data, None, ids.ctypes.data, None, None)
+        assert rc == n_expected_rc, raw5.lib.rt_last_error(raw5.ctx)
+        return rgb, ids
+
+    static(abi.RT_E_OVERFLOW)
+    assert b"may not allocate" in raw5.lib.rt_last_error(raw5.ctx)
+    rgb_a, t_a, id_a, _ = raw5.hw.color_at(o, d, 4, B.RenderOptions(jitter_mode=B.JITTER_CONST))
+    rgb_s, id_s = static(abi.RT_OK)
+    assert np.array_equal(rgb_a.view(np.uint32), rgb_s.view(np.uint32)) and np.array_equal(id_a, id_s)
+    ow = scene.build(_oracle().new_world())
+    rgb_r, t_r, id_r, _ = ow.color_at(o, d, 4, B.RenderOptions(jitter_mode=B.JITTER_CONST))
+    assert np.array_equal(id_a, id_r) and np.array_equal(t_a.view(np.uint32), t_r.view(np.uint32))
+    assert np.abs(to_u8(rgb_a).astype(int) - to_u8(rgb_r).astype(int)).max() <= 1
+
+    # the documented hard limit: with side lists capped below what the scene needs the failure is loud
+    monkeypatch.setenv("RT_SIDE_MAX", "100")
+    raw6 = Raw(scene, (64, 48))
+    rc = raw6.lib.rt_render(raw6.ctx, raw6.ds, C.byref(raw6.rcam), C.byref(opts), host_out.ctypes.data, None, None)
+    assert rc == abi.RT_E_OVERFLOW and b"RT_SIDE_MAX" in raw6.lib.rt_last_error(raw6.ctx)
+    monkeypatch.delenv("RT_SIDE_MAX")
+    ok = Raw(_GlassStack(30), (64, 48))  # another scene, another context: never needed any of it
     _, _, st2 = ok.render(mode=abi.RT_JITTER_CONST)
     assert st2.overflow == 0
-    host_out = np.zeros((48, 64, 3), dtype=np.float32)
-    rc = raw.lib.rt_render(raw.ctx, raw.ds, C.byref(raw.rcam), C.byref(opts), host_out.ctypes.data, None, None)
-    assert rc == abi.RT_E_OVERFLOW
+
+
+def test_transparent_triangle_soup_matches_oracle():
+    """400 glass triangles in a divided group between the camera and a wall: most rays cross dozens of them, refracted
+    rays list every crossing for the n1/n2 walk (intersections.rs:141-160), many more than RT_XS_CAP for the rays that
+    run along the pile.  The frame equals the oracle's: ids and t bit for bit, colours within the suite's bar."""
+    rng = np.random.RandomState(404)
+
+    def build(w):
+        glass = B.Material(color=(0.8, 0.9, 1.0), diffuse=0.2, ambient=0.1, transparency=0.85, reflective=0.1,
+                           refractive_index=1.3)
+        g = w.group([("rotate-y", 0.3)])
+        for k in range(400):
+            c = np.array([rng.uniform(-1.5, 1.5), rng.uniform(-1.0, 1.0), 0.03 * k])
+            p = [tuple(c + rng.uniform(-1.2, 1.2, 3) * (1, 1, 0.02)) for _ in range(3)]
+            w.group_add_shape(g, w.shape("triangle", (), glass, params=[x for q in p for x in q]))
+        w.group_divide(g, 8)
+        w.add_group(g)
+        w.add_shape(w.shape("plane", [("rotate-x", np.pi / 2), ("translate", 0, 0, 20)], B.Material(color=(1, 0.8, 0.6))))
+        w.add_point_light((-5, 8, -10), (1, 1, 1))
+        return w
+
+    cam = B.Camera(96, 64, 0.9, (0.2, 0.1, -3.0), (0, 0, 6.0), (0, 1, 0))
+    ro = B.RenderOptions(jitter_mode=B.JITTER_CONST)
+    rng = np.random.RandomState(404)
+    g = build(host.new_world(0)).render(cam, ro, aux=True)
+    rng = np.random.RandomState(404)
+    r = build(_oracle().new_world()).render(cam, ro, aux=True)
+    assert r.stats["refract"] > 1000
+    check(g, r, "triangle soup")
+    # and along the pile, where one ray meets nearly all 400: rt_color_at against the oracle
+    o = np.zeros((256, 3), dtype=np.float32)
+    o[:, 0] = np.linspace(-1.0, 1.0, 256)
+    o[:, 2] = -2.0
+    d = np.tile(np.array([[0.0, 0.0, 1.0]], dtype=np.float32), (256, 1))
+    d = d @ np.array([[np.cos(0.3), 0, -np.sin(0.3)], [0, 1, 0], [np.sin(0.3), 0, np.cos(0.3)]], dtype=np.float32).T
+    rng = np.random.RandomState(404)
+    gw = build(host.new_world(0))
+    rng = np.random.RandomState(404)
+    ow = build(_oracle().new_world())
+    grgb, gt, gid, _ = gw.color_at(o, d, 4)
+    rrgb, rt_, rid, _ = ow.color_at(o, d, 4)
+    assert np.array_equal(gid, rid) and np.array_equal(gt[rid >= 0].view(np.uint32), rt_[rid >= 0].view(np.uint32))
+    assert np.abs(to_u8(np.nan_to_num(grgb)).astype(int) - to_u8(np.nan_to_num(rrgb)).astype(int)).max() <= 1
 
 
 def test_abi_error_paths():
@@ -511,6 +610,17 @@ def test_abi_error_paths():
     bad2 = abi.RtScene.from_buffer_copy(fs)
     bad2.abi_version = 99
     assert lib.rt_scene_create(raw.ctx, C.byref(bad2), C.byref(ds)) == abi.RT_E_ABI
+    # a csg tree that could give one ray more intersections than the per-ray csg list holds (RT_CSG_CAP = 32: nine
+    # cylinders, four each) is refused when the scene is created -- never discovered ray by ray
+    w = host.new_world(0)
+    cyl = [w.shape("cylinder", [("translate", 0.3 * k, 0, 0)], None, params=[-1.0, 1.0, 1.0]) for k in range(9)]
+    tree = w.csg(B.CSG_UNION, B.CHILD_SHAPE, cyl[0], B.CHILD_SHAPE, cyl[1])
+    for k in range(2, 9):
+        tree = w.csg(B.CSG_UNION, B.CHILD_CSG, tree, B.CHILD_SHAPE, cyl[k])
+    w.add_csg(tree)
+    w.add_point_light((0, 5, -5), (1, 1, 1))
+    with pytest.raises(RuntimeError, match="RT_CSG_CAP"):
+        w.device_scene()
     # a part with no rows renders nothing and succeeds (ragged: 3 rows over 8 parts)
     scene3 = Raw(scene, (8, 3))
     rgb, _, st = scene3.render(tile_h=1, n_parts=8, part=5)
