@@ -1595,11 +1595,10 @@ __device__ __forceinline__ void pk_st3(const Park& pk, int k, V3 x) {
 
 // Persistent waves with a work queue: a wave draws its next items itself (one atomic per refill) instead of being
 // born for one tile, so heavy tiles do not leave CUs idle at the end of a frame and the grid is sized to the device,
-// not to the image.  Lanes that finish go idle; once RT_REFILL_MIN lanes of the wave are idle they take the next items
-// together.  Measured on dragons/cover at 4K: refilling partly idle waves (threshold 1..32) keeps more lanes busy but
-// mixes pixels of different tiles in one wave, and the loss of coherence in the traversal costs more than the idle
-// lanes did (4.8 / 4.7 / 4.5 / 4.3 ms for 1 / 8 / 32 / 64), so the default is 64: a wave takes a whole 8x8 tile
-// (64 consecutive items) when all its lanes are done.
+// not to the image.  Lanes that finish go idle; a wave takes a whole 8x8 tile (64 consecutive items) when all its lanes
+// are done.  Refilling partly idle waves was measured on dragons/cover at 4K: it keeps more lanes busy but mixes
+// pixels of different tiles in one wave, and the loss of coherence in the traversal costs more than the idle lanes did
+// (4.8 / 4.7 / 4.5 / 4.3 ms for a threshold of 1 / 8 / 32 / 64 idle lanes).
 // `Source` supplies the work: total(), start(item, ray) -> false if the item is outside the image, id(item) (the key
 // of the item's random numbers), first_hit(item, hit) and finish(item, colour, work).  `queue` is a zeroed counter in device memory.
 // Every wave leaves the loop: each refill advances the queue, and a wave whose lanes are all idle either refills
