@@ -408,31 +408,49 @@ __device__ __forceinline__ void load_tri(const Scene& sc, uint32_t prim, V3& p1,
 //  collect: every intersection with t <= tlimit (total order), for the n1/n2 container walk.
 // ---------------------------------------------------------------------------------------
 enum { SINK_CLOSEST = 0, SINK_COLLECT = 1, SINK_CLOSEST_NOSHADOW = 2, SINK_ANY_SHADOW = 3 };
-struct XsList {  // every intersection of a ray up to its hit: input of the n1/n2 walk
+#define RT_GLOBAL_AS __attribute__((address_space(1)))
+#define RT_XS_OVERFLOWED 0x7FFFFFFF
+// Every intersection of a ray up to its hit: input of the n1/n2 walk.  Two homes for it, chosen per KERNEL (template
+// parameter SIDE of integrate): RT_XS_CAP entries in per-lane scratch -- every normal launch -- or the lane's side list
+// in device memory, as long as the context says (Scene::side_cap), for the launches of a context one of whose rays has
+// passed RT_XS_CAP (rt_hip.hip grow_side; the reference's list is unbounded, intersections.rs:66-73).  Two kernels
+// rather than one list that continues in device memory: that version's extra branch in Sink::add, never taken, cost the
+// collect-heavy cover scene 19 % of its frame.
+struct XsList {
   float t[RT_XS_CAP];
   uint32_t s[RT_XS_CAP];
-  // entries RT_XS_CAP .. gcap-1 go to this lane's side list in device memory (gcap = 0: there is none); the
-  // reference's list is unbounded (intersections.rs:66-73)
-  float* gt;
-  uint32_t* gs;
-  int gcap;
+  __device__ __forceinline__ void attach(const Scene&) {}
+  __device__ __forceinline__ int capacity() const { return RT_XS_CAP; }
+  __device__ __forceinline__ void put(int c, float tt, uint32_t ss) {
+    t[c] = tt;
+    s[c] = ss;
+  }
 };
-#define RT_XS_OVERFLOWED 0x7FFFFFFF
-#ifndef RT_SIDE_XS
-#define RT_SIDE_XS 1
-#endif
-
 // A lane's side lists: [xs t | xs s | containers], side_cap entries each.
 enum { SIDE_XS_T = 0, SIDE_XS_S = 1, SIDE_CONTAINERS = 2, SIDE_LISTS = 3 };
 __device__ __forceinline__ char* side_list(const Scene& sc, int which) {
   const size_t lane = (size_t)blockIdx.x * RT_BLOCK + threadIdx.x;
   return sc.side + (lane * SIDE_LISTS + (size_t)which) * sc.side_cap * 4u;
 }
-__device__ __forceinline__ void xs_attach_side(const Scene& sc, XsList& xl) {
-  xl.gcap = (int)sc.side_cap;
-  xl.gt = sc.side_cap ? reinterpret_cast<float*>(side_list(sc, SIDE_XS_T)) : nullptr;
-  xl.gs = sc.side_cap ? reinterpret_cast<uint32_t*>(side_list(sc, SIDE_XS_S)) : nullptr;
-}
+struct XsSideList {
+  // (pointers into the GLOBAL address space, declared as such: a store through a generic pointer may alias the
+  // per-lane arrays and the LDS state as far as the compiler knows)
+  RT_GLOBAL_AS float* t;
+  RT_GLOBAL_AS uint32_t* s;
+  RT_GLOBAL_AS uint32_t* containers;
+  int cap;
+  __device__ __forceinline__ void attach(const Scene& sc) {
+    t = (RT_GLOBAL_AS float*)(uintptr_t)side_list(sc, SIDE_XS_T);
+    s = (RT_GLOBAL_AS uint32_t*)(uintptr_t)side_list(sc, SIDE_XS_S);
+    containers = (RT_GLOBAL_AS uint32_t*)(uintptr_t)side_list(sc, SIDE_CONTAINERS);
+    cap = (int)sc.side_cap;
+  }
+  __device__ __forceinline__ int capacity() const { return cap; }
+  __device__ __forceinline__ void put(int c, float tt, uint32_t ss) {
+    t[c] = tt;
+    s[c] = ss;
+  }
+};
 // Eight registers: the modes never need their private state at the same time, so it shares fields, and the
 // per-intersection decisions (takes / wants / add) are written as selects over those fields rather than as
 // branches on the mode: lanes of a wave are in different modes, and every branch costs exec-mask bookkeeping in the
@@ -441,12 +459,13 @@ __device__ __forceinline__ void xs_attach_side(const Scene& sc, XsList& xl) {
 //               A candidate counts only if it is positive, in front of `bound`, and before (t, shape) in (t, rank) order.
 //   bound       closest: nothing at or beyond it matters (NaN = no bound: t = +inf is a hit the reference shades)
 //               any-shadow: distance to the light, -inf once an occluder is found | collect: keep t <= bound
-struct Sink {
+template <class List>
+struct SinkT {
   float t;
   int shape;
   float a, b;    // closest: (u, v) of the best hit
   int c;         // collect: entries stored (RT_XS_OVERFLOWED: the list, side list included, overflowed)
-  XsList* xs;    // collect: where the entries go
+  List* xs;      // collect: where the entries go
   float bound;
   int mode;
   float lim;     // nothing beyond this t can matter any more (kept up to date by add); -inf: any-shadow found its occluder
@@ -465,7 +484,7 @@ struct Sink {
     bound = cap;
     lim = __builtin_fminf(t, cap);
   }
-  __device__ __forceinline__ void init_collect(XsList* xs_, float tlimit_) {
+  __device__ __forceinline__ void init_collect(List* xs_, float tlimit_) {
     init(SINK_COLLECT);
     xs = xs_;
     bound = tlimit_;
@@ -487,7 +506,6 @@ struct Sink {
   __device__ __forceinline__ bool found() const { return lim == -__builtin_inff(); }
   __device__ __forceinline__ int count() const { return c == RT_XS_OVERFLOWED ? 0 : c; }
   __device__ __forceinline__ int overflow() const { return c == RT_XS_OVERFLOWED ? 1 : 0; }
-  __device__ __forceinline__ bool spilled() const { return c > RT_XS_CAP && c != RT_XS_OVERFLOWED; }
   // does this traversal look at a shape with these flags at all?
   __device__ __forceinline__ bool takes(uint32_t kind_flags) const {
     return (kind_flags & RT_SHAPE_SHADOW) ? mode != SINK_CLOSEST_NOSHADOW : mode != SINK_ANY_SHADOW;
@@ -500,13 +518,8 @@ struct Sink {
   __device__ __forceinline__ void add(float tt, uint32_t s, float uu, float vv) {
     if (!wants(tt, s)) return;
     if (mode == SINK_COLLECT) {
-      if (c < RT_XS_CAP) {
-        xs->t[c] = tt;
-        xs->s[c] = s;
-        c++;
-      } else if (RT_SIDE_XS && c < xs->gcap) {  // past the per-lane list: the side list in device memory, if the context has one
-        xs->gt[c] = tt;
-        xs->gs[c] = s;
+      if (c < xs->capacity()) {
+        xs->put(c, tt, s);
         c++;
       } else {
         c = RT_XS_OVERFLOWED;
@@ -525,6 +538,7 @@ struct Sink {
   __device__ __forceinline__ bool wants_negative() const { return mode == SINK_COLLECT; }
   __device__ __forceinline__ bool done() const { return mode == SINK_ANY_SHADOW && found(); }
 };
+typedef SinkT<XsList> Sink;
 
 // The shape reported for a hit on `s`: the last of its value-identical duplicates (rt_scene_create; triangles only,
 // the index sits in the record's unused min slot).  Shading does not care which of them it is.
@@ -607,8 +621,9 @@ __device__ __forceinline__ bool entry_less(float ta, uint32_t sa, float tb, uint
   return of_gt(tb, ta) || (of_eq(ta, tb) && sa < sb);
 }
 // Drop an entry that is == its successor (BTreeMap bulk build).
-template <int VARIANT = 0>
-__device__ inline int dedup_sorted(const Scene& sc, float* t, uint32_t* s, int lo, int hi) {
+// (FP / UP: pointers to float / uint32_t in whatever address space the list lives in)
+template <class FP, class UP>
+__device__ inline int dedup_sorted(const Scene& sc, FP t, UP s, int lo, int hi) {
   int w = lo;
   for (int i = lo; i < hi; i++) {
     if (i + 1 < hi && of_eq(t[i], t[i + 1]) && vclass_eq(cst(sc.shapes)[s[i]].vclass, cst(sc.shapes)[s[i + 1]].vclass)) continue;
@@ -618,8 +633,8 @@ __device__ inline int dedup_sorted(const Scene& sc, float* t, uint32_t* s, int l
   }
   return w;
 }
-template <int VARIANT = 0>
-__device__ inline void sort_entries(float* t, uint32_t* s, int lo, int hi) {
+template <class FP, class UP>
+__device__ inline void sort_entries(FP t, UP s, int lo, int hi) {
   for (int i = lo + 1; i < hi; i++) {
     float ti = t[i];
     uint32_t si = s[i];
@@ -660,8 +675,8 @@ __device__ inline void csg_eval(const Scene& sc, RtCsgRoot root, const Ray& ray,
     }
     if (flags & RT_CSG_LEFT_IS_SHAPE) shape_intersect(sc, w2.x, ray, L);
     if (flags & RT_CSG_RIGHT_IS_SHAPE) shape_intersect(sc, w2.y, ray, L);
-    sort_entries(L.t, L.s, start, L.n);
-    L.n = dedup_sorted(sc, L.t, L.s, start, L.n);
+    sort_entries(&L.t[0], &L.s[0], start, L.n);
+    L.n = dedup_sorted(sc, &L.t[0], &L.s[0], start, L.n);
     // filter_intersections (csg.rs:51-72)
     bool in_l = false, in_r = false;
     int w = start;
@@ -686,7 +701,7 @@ __device__ inline void csg_eval(const Scene& sc, RtCsgRoot root, const Ray& ray,
       else
         in_r = !in_r;
     }
-    L.n = dedup_sorted(sc, L.t, L.s, start, w);  // `result.into()` (csg.rs:71)
+    L.n = dedup_sorted(sc, &L.t[0], &L.s[0], start, w);  // `result.into()` (csg.rs:71)
     seg[sp++] = start;
   }
 }
@@ -734,7 +749,7 @@ __device__ __forceinline__ bool aux_gate(const Scene& sc, uint32_t g, uint32_t r
   return true;
 }
 // false: this ray must take the reference walk through the subtree (nothing has been added to the sink)
-template <bool COUNT>
+template <bool COUNT, class Sink>
 __device__ inline bool aux_intersect(const Scene& sc, uint32_t root_node, uint32_t aux_root, const Ray& cur, Sink& sink,
                                      Counters& cn) {
   // the nesting argument behind aux_gate needs one axis on the non-parallel branch of check_axis
@@ -859,16 +874,16 @@ __device__ inline bool aux_intersect(const Scene& sc, uint32_t root_node, uint32
 // The winner's (u, v) are not carried: the shading step recomputes them for smooth triangles (same arithmetic).
 // ---------------------------------------------------------------------------------------
 #ifndef RT_STEAL_MIN_IDLE
-#define RT_STEAL_MIN_IDLE 24  // lanes without work before the wave looks for work to hand out
+#define RT_STEAL_MIN_IDLE 16  // lanes without work before the wave looks for work to hand out
 #endif
 #ifndef RT_STEAL_PERIOD
-#define RT_STEAL_PERIOD 2     // ... every this many steps
+#define RT_STEAL_PERIOD 1     // ... every this many steps
 #endif
 #ifndef RT_STEAL_MAX_PAIRS
 #define RT_STEAL_MAX_PAIRS 16
 #endif
 #ifndef RT_LEAF_BATCH
-#define RT_LEAF_BATCH 24      // lanes waiting at a leaf that start a leaf step while others could still descend
+#define RT_LEAF_BATCH 32      // lanes waiting at a leaf that start a leaf step while others could still descend
 #endif
 __device__ __forceinline__ unsigned long long* aux_keys() {
   __shared__ unsigned long long keys[RT_BLOCK];
@@ -885,7 +900,7 @@ __device__ __forceinline__ uint32_t pull_u(int lane, uint32_t v) {
 }
 // want: this lane's ray reached the subtree root (wave-uniform root_node / aux_root).  handled (for lanes that want):
 // false = this ray must take the reference walk through the subtree.  Every lane of the wave must call.
-template <bool COUNT>
+template <bool COUNT, class Sink>
 __device__ inline void aux_coop(const Scene& sc, const uint32_t root_node, const uint32_t aux_root, const Ray& cur, Sink& sink,
                                 Counters& cn, const bool want, bool& handled) {
   const f4n RT_CONST_AS* A = cst(reinterpret_cast<const f4n*>(sc.aux_nodes)) + 5u * (size_t)aux_root;
@@ -893,13 +908,26 @@ __device__ inline void aux_coop(const Scene& sc, const uint32_t root_node, const
   // ---- the task of this lane's own ray (see aux_intersect for the bounds behind the numbers) ----
   Ray T = cur;
   float Tkmax, Tpadk;
+  // values derived from the task's ray; recomputed after a steal
+  float dm, inv_dm, lo0;
+  V3 dn, inv;
+  bool use_cone;
+  auto derive = [&]() {
+    dm = magnitude(T.d);
+    Tkmax = 1e4f * h1.y * dm;
+    inv_dm = __builtin_amdgcn_rcpf(dm) * 1.000001f;
+    dn = inv_dm * T.d;  // feeds the cone bound only (6 % slack there): no need for three IEEE divisions
+    use_cone = Tpadk * Tkmax > RT_CONE_MIN_PAD * h1.x;
+    inv = v3(__builtin_amdgcn_rcpf(T.d.x), __builtin_amdgcn_rcpf(T.d.y), __builtin_amdgcn_rcpf(T.d.z));
+    lo0 = 0.f;  // closest / shadow searches never want t <= 0
+  };
   bool work;
   {
     const bool axis_ok = __builtin_fabsf(cur.d.x) >= 1e-4f || __builtin_fabsf(cur.d.y) >= 1e-4f || __builtin_fabsf(cur.d.z) >= 1e-4f;
     const V3 oc = cur.o - v3(h0.x, h0.y, h0.z);
     const float S = magnitude(oc) + h0.w;
-    Tkmax = 1e4f * h1.y * magnitude(cur.d);
     Tpadk = 1.43e-6f * (S + h1.x);
+    derive();
     work = want && axis_ok && (Tpadk * Tkmax < __builtin_inff());
   }
   handled = work;
@@ -910,19 +938,6 @@ __device__ inline void aux_coop(const Scene& sc, const uint32_t root_node, const
   unsigned long long* keys = aux_keys();
   const unsigned long long key0 = hit_key(sink.t, sink.shape);
   if (work) __hip_atomic_store(&keys[Towner], key0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  // values derived from the task's ray; recomputed after a steal
-  float dm, inv_dm, lo0;
-  V3 dn, inv;
-  bool use_cone;
-  auto derive = [&]() {
-    dm = magnitude(T.d);
-    dn = T.d / dm;
-    inv_dm = __builtin_amdgcn_rcpf(dm) * 1.000001f;
-    use_cone = Tpadk * Tkmax > RT_CONE_MIN_PAD * h1.x;
-    inv = v3(__builtin_amdgcn_rcpf(T.d.x), __builtin_amdgcn_rcpf(T.d.y), __builtin_amdgcn_rcpf(T.d.z));
-    lo0 = 0.f;  // closest / shadow searches never want t <= 0
-  };
-  derive();
   uint32_t* stk = aux_stack();
   int sp = 0, bot = 0;  // deferred subtrees of this lane: rows [bot, sp) of its column
   uint32_t ref = __float_as_uint(h1.z) << 4;
@@ -1013,16 +1028,21 @@ __device__ inline void aux_coop(const Scene& sc, const uint32_t root_node, const
     if (n_idle >= RT_STEAL_MIN_IDLE && (iter % RT_STEAL_PERIOD) == 0u) {
       unsigned long long donors = __builtin_amdgcn_ballot_w64(work && sp > bot);
       if (donors != 0ull) {
-        unsigned long long idle = ~busy;
-        int victim = -1;     // thief: the lane it takes from
-        bool gives = false;  // donor: its bottom entry goes to a thief
-        for (int pair = 0; pair < RT_STEAL_MAX_PAIRS && donors != 0ull && idle != 0ull; pair++) {
-          const uint32_t d = (uint32_t)__builtin_ctzll(donors), th = (uint32_t)__builtin_ctzll(idle);
-          donors &= donors - 1ull;
-          idle &= idle - 1ull;
-          if (lane == th) victim = (int)d;
-          if (lane == d) gives = true;
-        }
+        // Pairing: the r-th idle lane takes from the r-th donor.  Ranks come from the ballot masks (mbcnt); the donors'
+        // lane numbers are compacted to the low lanes with one ds_permute (every lane pushes its number: donors to
+        // their rank, the others to the remaining slots from the top, a bijection), and a thief pulls its victim's
+        // number from the lane of its own rank.  (A serial loop over pairs cost ~4 vector instructions per pair.)
+        const unsigned long long idle = ~busy;
+        const uint32_t n_donors = (uint32_t)__builtin_popcountll(donors);
+        const uint32_t rd = __builtin_amdgcn_mbcnt_hi((uint32_t)(donors >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)donors, 0u));
+        const uint32_t ri = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+        const bool is_donor = ((donors >> lane) & 1ull) != 0ull;
+        const uint32_t dest = is_donor ? rd : 63u - (lane - rd);
+        const uint32_t compact = (uint32_t)__builtin_amdgcn_ds_permute((int)(dest << 2), (int)lane);
+        const uint32_t donor_of_rank = pull_u((int)(ri & 63u), compact);
+        const bool steals = !work && ri < n_donors;
+        const int victim = steals ? (int)donor_of_rank : -1;  // thief: the lane it takes from
+        const bool gives = is_donor && rd < n_idle;           // donor: its bottom entry goes to a thief
         uint32_t entry = 0u;
         if (gives) {
           entry = stk[bot * RT_BLOCK];
@@ -1034,16 +1054,15 @@ __device__ inline void aux_coop(const Scene& sc, const uint32_t root_node, const
         const uint32_t e = pull_u(src, entry);
         const float ox = pull_f(src, T.o.x), oy = pull_f(src, T.o.y), oz = pull_f(src, T.o.z);
         const float dx = pull_f(src, T.d.x), dy = pull_f(src, T.d.y), dz = pull_f(src, T.d.z);
-        const float km = pull_f(src, Tkmax), pk = pull_f(src, Tpadk), bd = pull_f(src, Tbound);
-        const uint32_t ow = pull_u(src, Towner), md = pull_u(src, (uint32_t)Tmode);
+        const float pk = pull_f(src, Tpadk), bd = pull_f(src, Tbound);
+        const uint32_t om = pull_u(src, Towner | ((uint32_t)Tmode << 16));  // owner (< RT_BLOCK) and mode in one word
         if (victim >= 0) {
           T = Ray{v3(ox, oy, oz), v3(dx, dy, dz)};
-          Tkmax = km;
           Tpadk = pk;
           Tbound = bd;
-          Towner = ow;
-          Tmode = (int)md;
-          derive();
+          Towner = om & 0xFFFFu;
+          Tmode = (int)(om >> 16);
+          derive();  // (Tkmax too: the owner's expression on the owner's values, the same bits, one pull less)
           ref = e;
           sp = bot = 0;
           work = true;
@@ -1101,7 +1120,7 @@ __device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballo
 #ifndef RT_WI_INLINE
 #define RT_WI_INLINE inline
 #endif
-template <bool COUNT, bool CULL>
+template <bool COUNT, bool CULL, class Sink>
 __device__ RT_WI_INLINE void world_intersect(const Scene& sc, const Ray& ray, Sink& sink, Counters& cn,
                                              const bool active = true) {
   // `active` false: this lane has no ray to trace but still takes part in the wave-wide votes of the walk
@@ -1523,11 +1542,11 @@ enum { ST_TRACE = 0, ST_NEXT_LIGHT, ST_LIGHTS_DONE, ST_SECONDARY, ST_NEXT_RAY, S
 
 // The n1/n2 walk of Computations::prepare (intersections.rs:141-160) over the sorted,
 // de-duplicated list of every intersection up to the hit.
-template <int VARIANT = 0>
-__device__ inline void refractive_indices(const Scene& sc, float* ts, uint32_t* ss, uint32_t* containers, int count,
+template <class FP, class UP>
+__device__ inline void refractive_indices(const Scene& sc, FP ts, UP ss, UP containers, int count,
                                           float hit_t, int hit_shape, float& n1, float& n2) {
-  sort_entries<VARIANT>(ts, ss, 0, count);
-  int n = dedup_sorted<VARIANT>(sc, ts, ss, 0, count);
+  sort_entries(ts, ss, 0, count);
+  int n = dedup_sorted(sc, ts, ss, 0, count);
   n1 = 1.f;
   n2 = 1.f;
   int nc = 0;
@@ -1553,21 +1572,15 @@ __device__ inline void refractive_indices(const Scene& sc, float* ts, uint32_t* 
     if (is_hit && nc > 0) n2 = cst(sc.materials)[cst(sc.shapes)[containers[nc - 1]].material].refractive_index;
   }
 }
-// The n1/n2 walk over what a COLLECT traversal left in `xl` (sink.c entries).  A list that went past RT_XS_CAP continues
-// in the lane's side list: its first RT_XS_CAP entries are copied there and the walk runs in device memory.
-__device__ inline void refractive_indices_of(const Scene& sc, XsList& xl, const Sink& sink, float hit_t, int hit_shape,
-                                             float& n1, float& n2) {
-  if (RT_SIDE_XS && sink.spilled()) {
-    for (int i = 0; i < RT_XS_CAP; i++) {
-      xl.gt[i] = xl.t[i];
-      xl.gs[i] = xl.s[i];
-    }
-    refractive_indices<1>(sc, xl.gt, xl.gs, reinterpret_cast<uint32_t*>(side_list(sc, SIDE_CONTAINERS)), sink.c, hit_t,
-                          hit_shape, n1, n2);
-  } else {
-    uint32_t containers[RT_XS_CAP];
-    refractive_indices<0>(sc, xl.t, xl.s, containers, sink.count(), hit_t, hit_shape, n1, n2);
-  }
+// The n1/n2 walk over what a COLLECT traversal left in `xl` (count entries), in the list's own memory.
+__device__ inline void refractive_indices_of(const Scene& sc, XsList& xl, int count, float hit_t, int hit_shape, float& n1,
+                                             float& n2) {
+  uint32_t containers[RT_XS_CAP];
+  refractive_indices(sc, &xl.t[0], &xl.s[0], &containers[0], count, hit_t, hit_shape, n1, n2);
+}
+__device__ inline void refractive_indices_of(const Scene& sc, XsSideList& xl, int count, float hit_t, int hit_shape, float& n1,
+                                             float& n2) {
+  refractive_indices(sc, xl.t, xl.s, xl.containers, count, hit_t, hit_shape, n1, n2);
 }
 
 // Register budget: the traversal alone needs ~100 VGPRs and the kernel is built for 128 (four waves per SIMD), so the
@@ -1605,12 +1618,22 @@ __device__ __forceinline__ void pk_st3(const Park& pk, int k, V3 x) {
 // or, once the queue has run past total(), breaks.
 #define RT_QUEUE_STRIDE 8  // u64 slots between the queues of two classes (64 B: one atomic unit each)
 enum { ST_IDLE = 100 };
-template <bool COUNT, bool CULL, class Source>
+template <bool v, class A, class B>
+struct Pick {
+  typedef A type;
+};
+template <class A, class B>
+struct Pick<false, A, B> {
+  typedef B type;
+};
+// SIDE: the n1/n2 lists live in the context's side lists (see XsList)
+template <bool COUNT, bool CULL, bool SIDE, class Source>
 __device__ inline void integrate(const Scene& sc, const RenderParams& rp, const Source& src, uint32_t remaining0,
                                  unsigned long long* queue, Counters& cn) {
   PendingRay stack[RT_MAX_RAY_STACK];
-  XsList xl;
-  xs_attach_side(sc, xl);
+  typedef typename Pick<SIDE, XsSideList, XsList>::type List;
+  List xl;
+  xl.attach(sc);
   Park pk{threadIdx.x};
   int sp = 0;
   bool first = true;
@@ -1707,7 +1730,7 @@ __device__ inline void integrate(const Scene& sc, const RenderParams& rp, const 
     }
     const bool active = st != ST_IDLE;
     // ---------------- the one traversal ----------------
-    Sink sink;
+    SinkT<List> sink;
     if (job == JOB_COLLECT)
       sink.init_collect(&xl, hit_t);
     else if (job == JOB_SHADOW && (sc.props & RT_SCENE_HAS_NOSHADOW) && !(sc.props & RT_SCENE_SHADOW_TWO_PASS)) {
@@ -1860,7 +1883,7 @@ __device__ inline void integrate(const Scene& sc, const RenderParams& rp, const 
       }
     } else {  // JOB_COLLECT
       cn.overflow += sink.overflow();
-      refractive_indices_of(sc, xl, sink, hit_t, hit_shape, n1, n2);
+      refractive_indices_of(sc, xl, sink.count(), hit_t, hit_shape, n1, n2);
       st = ST_SECONDARY;
     }
 
@@ -2148,14 +2171,12 @@ __device__ __forceinline__ V3 color_at_direct(const Scene& sc, const RenderParam
     float reflectance = 1.f, transmittance = 1.f;
     float n1 = 1.f, n2 = 1.f;
     if (want_refract && !(sc.props & RT_SCENE_RI_ALL_ONE)) {
-      XsList xl;
-      xl.gcap = 0;  // no side lists in this kernel (simple_intersect)
+      XsList xl;  // (no side lists in this kernel: a context that has them renders through the persistent one)
       Sink cs;
       cs.init_collect(&xl, hit.t);
       simple_intersect<COUNT>(sc, ray, cs, cn);
       cn.overflow += cs.overflow();
-      uint32_t containers[RT_XS_CAP];
-      refractive_indices<0>(sc, xl.t, xl.s, containers, cs.count(), hit.t, hit.shape, n1, n2);
+      refractive_indices_of(sc, xl, cs.count(), hit.t, hit.shape, n1, n2);
     }
     if (m_reflective > 0.f && m_transparency > 0.f) {  // Computations::schlick (intersections.rs:177-192)
       float cosv = dot(eyev, normalv);

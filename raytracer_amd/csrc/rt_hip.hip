@@ -184,7 +184,7 @@ struct PixelSource {
     write_colour<COUNT>(*sc, o, (size_t)ly * cam.hsize + px, col, (float)work, ws, wc);
   }
 };
-template <bool COUNT, bool CULL>
+template <bool COUNT, bool CULL, bool SIDE = false>
 __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAVES_PER_EU, RT_WAVES_PER_EU)))
 void k_render_jobs(Scene sc, RtCamera cam, RenderParams rp, PartInfo part, PixelOut o, unsigned long long* counters) {
 #ifdef RT_PHASE_TIMERS
@@ -192,7 +192,7 @@ void k_render_jobs(Scene sc, RtCamera cam, RenderParams rp, PartInfo part, Pixel
 #endif
   PixelSource<COUNT> src{&sc, cam, part, o, (cam.hsize + 8u * RT_SUPER - 1u) / (8u * RT_SUPER), (part.rows + 8u * RT_SUPER - 1u) / (8u * RT_SUPER)};
   Counters cn = {};
-  integrate<COUNT, CULL>(sc, rp, src, sc.recursion_limit, counters + RT_QUEUE_SLOT, cn);
+  integrate<COUNT, CULL, SIDE>(sc, rp, src, sc.recursion_limit, counters + RT_QUEUE_SLOT, cn);
 #ifdef RT_PHASE_TIMERS
   if ((threadIdx.x & 63) == 0) atomicAdd(counters + 14, (unsigned long long)(__builtin_readcyclecounter() - t_pixel0));
 #endif
@@ -268,12 +268,12 @@ struct RaySource {
   __device__ void first_hit(uint32_t i, const Hit& ph) const { write_ray_hit(o, i, ph); }
   __device__ void finish(uint32_t i, V3 col, uint32_t, Counters&) const { write_ray_colour(o, i, col); }
 };
-template <bool COUNT, bool CULL>
+template <bool COUNT, bool CULL, bool SIDE = false>
 __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAVES_PER_EU, RT_WAVES_PER_EU)))
 void k_color_at_jobs(Scene sc, RenderParams rp, RayOut o, uint32_t remaining, unsigned long long* counters) {
   RaySource src{o};
   Counters cn = {};
-  integrate<COUNT, CULL>(sc, rp, src, remaining, counters + RT_QUEUE_SLOT, cn);
+  integrate<COUNT, CULL, SIDE>(sc, rp, src, remaining, counters + RT_QUEUE_SLOT, cn);
   flush_counters(cn, counters, sc.sticky);
 }
 __global__ __launch_bounds__(RT_BLOCK) void k_color_at_direct(Scene sc, RenderParams rp, RayOut o, uint32_t remaining,
@@ -1002,6 +1002,9 @@ static int launch_part(RtContext* ctx, const Scene& sc, const RtCamera* cam, con
     const bool cull = (sc.props & RT_SCENE_SHAPE_CULL) != 0;  // the scene has cull records (rt_scene_create)
     auto kern = count ? (cull ? k_render_jobs<true, true> : k_render_jobs<true, false>)
                       : (cull ? k_render_jobs<false, true> : k_render_jobs<false, false>);
+    // a context with side lists: the one instantiation that keeps the n1/n2 lists there (it counts work and tests cull
+    // records whether asked to or not: it is the slow path, and one kernel instead of four keeps the build short)
+    if (sc.side_cap) kern = k_render_jobs<true, true, true>;
     // A scene of a few shapes has cheap tiles throughout, and its frame time is the queue's atomics: draw up to
     // RT_LIGHT_SCENE_CHUNK tiles at a time, as long as every wave still gets RT_LIGHT_SCENE_DRAWS draws
     // (integrate's refill).
@@ -1237,6 +1240,7 @@ trace_again:
     const bool cull = (sc.props & RT_SCENE_SHAPE_CULL) != 0;
     auto kern = (sc.flags & RT_RENDER_COUNT_WORK) ? (cull ? k_color_at_jobs<true, true> : k_color_at_jobs<true, false>)
                                                   : (cull ? k_color_at_jobs<false, true> : k_color_at_jobs<false, false>);
+    if (sc.side_cap) kern = k_color_at_jobs<true, true, true>;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(RT_BLOCK), 0, ctx->stream, sc, rp, ro, remaining, block);
   }
   HIP_TRY(ctx, hipGetLastError());

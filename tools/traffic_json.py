@@ -8,13 +8,13 @@ import sys
 text = open(sys.argv[1]).read()
 vals = {}
 for line in text.splitlines():
-    m = re.match(r"(.*k_render_jobs<false, false>.*?)\s+(FETCH_SIZE|WRITE_SIZE)\s+(\d+)\s+([\d.]+)", line)
+    m = re.match(r"(.*k_render_jobs<false, false, false>.*?)\s+(FETCH_SIZE|WRITE_SIZE)\s+(\d+)\s+([\d.]+)", line)
     if m:
         vals[m.group(2)] = (float(m.group(4)), int(m.group(3)))
 bench = [json.loads(ln) for ln in text.splitlines() if ln.startswith('{"metric"')]
 wl = bench[-1]["config"]["workload"].split(" recursion_limit")[0] if bench else "?"
 print(json.dumps({
-    "workload": wl, "parts": 1, "kernel": "k_render_jobs<false, false>",
+    "workload": wl, "parts": 1, "kernel": "k_render_jobs<false, false, false>",
     "fetch_kb": vals.get("FETCH_SIZE", (None,))[0], "write_kb": vals.get("WRITE_SIZE", (None,))[0],
     "source": f"{sys.argv[2]} (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, per dispatch average of "
               f"{vals.get('FETCH_SIZE', (0, 0))[1]})",
