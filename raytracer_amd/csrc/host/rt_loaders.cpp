@@ -313,11 +313,65 @@ int ppm_decode(const uint8_t* data, size_t len, uint32_t* w, uint32_t* h, std::v
   rgb.resize(n);
   const float mv = (float)maxval;
   if (ascii) {
-    for (size_t i = 0; i < n; i++) {
-      uint32_t v;
-      if (!ppm_uint(p, e, &v)) return fail("PPM: fewer samples than the header promises");
-      if (v > maxval) return fail("PPM: sample above maxval");
-      rgb[i] = (float)v / mv;  // canvas.rs:99-101: u8 sample as f32 / maxval as f32
+    // the samples, on threads: the body is cut at line ends (a comment never crosses one), every piece counts its
+    // samples, then parses them to where they belong
+    const int nt = thread_count(0, (size_t)(e - p), 1u << 20);
+    struct Piece {
+      const uint8_t *b, *e;
+      size_t count = 0, first = 0;
+      int error = 0;  // 1: not a number, 2: above maxval
+    };
+    std::vector<Piece> pieces((size_t)nt);
+    {
+      const uint8_t* q = p;
+      for (int k = 0; k < nt; k++) {
+        const uint8_t* want = k + 1 == nt ? e : p + (size_t)(e - p) * (size_t)(k + 1) / (size_t)nt;
+        if (want < q) want = q;
+        if (want < e) {
+          const uint8_t* nl = static_cast<const uint8_t*>(std::memchr(want, '\n', (size_t)(e - want)));
+          want = nl ? nl + 1 : e;
+        }
+        pieces[k].b = q;
+        pieces[k].e = want;
+        q = want;
+      }
+    }
+    auto on_threads = [&](auto&& fn) {
+      if (nt == 1) return fn(pieces[0]);
+      std::vector<std::thread> pool;
+      for (int k = 0; k < nt; k++) pool.emplace_back([&, k] { fn(pieces[k]); });
+      for (auto& t : pool) t.join();
+    };
+    on_threads([](Piece& pc) {
+      const uint8_t* q = pc.b;
+      const uint8_t *tb, *te;
+      while (ppm_token(q, pc.e, &tb, &te)) pc.count++;
+    });
+    size_t total = 0;
+    for (Piece& pc : pieces) {
+      pc.first = total;
+      total += pc.count;
+    }
+    if (total < n) return fail("PPM: fewer samples than the header promises");
+    float* out = rgb.data();
+    on_threads([&](Piece& pc) {
+      const uint8_t* q = pc.b;
+      for (size_t i = pc.first; i < pc.first + pc.count && i < n; i++) {
+        uint32_t v;
+        if (!ppm_uint(q, pc.e, &v)) {
+          pc.error = 1;
+          return;
+        }
+        if (v > maxval) {
+          pc.error = 2;
+          return;
+        }
+        out[i] = (float)v / mv;  // canvas.rs:99-101: u8 sample as f32 / maxval as f32
+      }
+    });
+    for (const Piece& pc : pieces) {
+      if (pc.error == 1) return fail("PPM: malformed sample");
+      if (pc.error == 2) return fail("PPM: sample above maxval");
     }
   } else {
     p++;  // the single whitespace byte after maxval

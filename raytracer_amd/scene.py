@@ -174,8 +174,17 @@ class Scene:
         self._define_materials: Dict[str, list] = {}
         self._images: Dict[str, int] = {}
         self._mesh_cache: Dict[str, list] = {}
+        # On the product path (a HostWorld) files go through the native loaders of include/rt_loaders.h; the oracle's
+        # world is fed by the Python readers of this package (tests/test_loaders.py holds the two against each other)
+        self._native = hasattr(wb, "device_scene")
+        self._obj_bytes: Dict[str, bytes] = {}
         for name, path in self.ppm_files.items():
-            self._images[name] = wb.uv_image(read_ppm(path))
+            if self._native:
+                from . import loaders
+                with open(path, "rb") as f:
+                    self._images[name] = loaders.uv_image_ppm(wb, f.read())
+            else:
+                self._images[name] = wb.uv_image(read_ppm(path))
         for ins in self.instructions:
             if "define" in ins and "add" not in ins:
                 self._define(ins)
@@ -295,7 +304,16 @@ class Scene:
         wb = self._wb
         ops, mat = self._transform_material(ins)
         g = wb.group(())
-        if ins.get("obj") is not None:
+        if ins.get("obj") is not None and self._native and ins["obj"] not in self.meshes:
+            from . import loaders
+            name = ins["obj"]
+            if name not in self._obj_bytes:
+                if name not in self.obj_files:
+                    raise FileNotFoundError(f"Couldn't find file named {name}")
+                with open(self.obj_files[name], "rb") as f:
+                    self._obj_bytes[name] = f.read()
+            loaders.group_add_obj(wb, g, mat, self._obj_bytes[name])  # parse_obj (obj.rs:8-41), natively
+        elif ins.get("obj") is not None:
             for og in self._mesh(ins["obj"]):  # parse_obj (obj.rs:8-41): one child group per OBJ group
                 wb.group_add_mesh(g, mat, og["positions"], og["normals"], og["vidx"], og["nidx"])
         wb.group_set_transform(g, ops)  # `.with_transform(transform)` (scene.rs:602)

@@ -232,3 +232,24 @@ def test_ppm_encode_is_the_python_writer_and_reads_back(tmp_path, threads):
     assert (tmp_path / "native.ppm").read_bytes() == text
     with pytest.raises(RuntimeError, match="cannot open"):
         loaders.ppm_write(str(tmp_path / "no_such_dir" / "x.ppm"), u8)
+
+
+def test_large_ascii_ppm_is_decoded_in_pieces():
+    """A P3 body of several MB is cut at line ends and parsed on threads: every sample lands where it belongs, comments
+    and ragged lines included."""
+    rng = np.random.RandomState(12)
+    h, w = 512, 1024
+    px = rng.randint(0, 256, size=h * w * 3)
+    lines, i = [], 0
+    while i < len(px):
+        n = int(rng.randint(1, 40))
+        lines.append(" ".join(str(int(v)) for v in px[i:i + n]) + (" # c 1 2 3" if len(lines) % 11 == 0 else ""))
+        i += n
+    data = (f"P3\n{w} {h}\n255\n" + "\n".join(lines) + "\n").encode()
+    assert len(data) > 4 << 20
+    img = loaders.ppm_decode(data)
+    assert np.array_equal(img.reshape(-1), px.astype(np.float32) / np.float32(255))
+    with pytest.raises(RuntimeError, match="fewer samples"):
+        loaders.ppm_decode(data[: len(data) - 200000])
+    with pytest.raises(RuntimeError, match="malformed sample|above maxval"):
+        loaders.ppm_decode(data.replace(b" 17 ", b" 1x7 ", 1) if b" 17 " in data else data[:-10] + b" zz\n")
