@@ -443,14 +443,18 @@ class _GlassStack:
     """n parallel glass panes (planes facing the camera, refractive index 1.5), the camera between two of them near the
     far end: the n1/n2 walk of a hit (intersections.rs:141-160) lists every pane behind the eye as well."""
 
-    def __init__(self, n):
+    def __init__(self, n, area_light=False):
         self.n = n
+        self.area_light = area_light
 
     def build(self, w):
         glass = B.Material(color=(0.9, 0.9, 1.0), diffuse=0.1, transparency=0.9, reflective=0.1, refractive_index=1.5)
         for k in range(self.n):
             w.add_shape(w.shape("plane", [("rotate-x", np.pi / 2), ("translate", 0, 0, 0.01 * k)], glass))
-        w.add_point_light((0, 5, -10), (1, 1, 1))
+        if self.area_light:  # group-less with an area light: the direct kernel (rt_hip.hip launch_part)
+            w.add_area_light((-1, 5, -10), (2, 0, 0), 2, (0, 2, 0), 2, (1, 1, 1))
+        else:
+            w.add_point_light((0, 5, -10), (1, 1, 1))
         return w
 
     def camera(self, hsize, vsize):
@@ -494,6 +498,15 @@ def test_overflow_is_never_silent(monkeypatch):
     raw3 = Raw(scene, (64, 48))
     rc = raw3.lib.rt_render(raw3.ctx, raw3.ds, C.byref(raw3.rcam), C.byref(opts), host_out.ctypes.data, None, None)
     assert rc == abi.RT_OK and same(host_out)
+
+    # the same through the direct kernel (group-less world, area light), which has no side lists of its own: the call
+    # that overflows there runs again in the persistent kernel
+    area = _GlassStack(140, area_light=True)
+    want_a = area.build(_oracle().new_world()).render(area.camera(64, 48), B.RenderOptions(jitter_mode=B.JITTER_CONST), aux=True)
+    raw_a = Raw(area, (64, 48))
+    rgb, ids, st = raw_a.render(mode=abi.RT_JITTER_CONST)
+    d = np.abs(to_u8(rgb).astype(int) - to_u8(want_a.rgb).astype(int)).max(axis=2)
+    assert st.overflow == 0 and float((d <= 1).mean()) >= LSB_FRACTION and np.array_equal(ids, want_a.object_id)
 
     # an earlier asynchronous overflow is reported by the next synchronous call even though that call itself succeeds
     raw4 = Raw(scene, (64, 48))
