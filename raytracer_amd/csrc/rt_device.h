@@ -883,7 +883,7 @@ __device__ inline bool aux_intersect(const Scene& sc, uint32_t root_node, uint32
 #define RT_STEAL_MAX_PAIRS 16
 #endif
 #ifndef RT_LEAF_BATCH
-#define RT_LEAF_BATCH 32      // lanes waiting at a leaf that start a leaf step while others could still descend
+#define RT_LEAF_BATCH 40      // lanes waiting at a leaf that start a leaf step while others could still descend
 #endif
 __device__ __forceinline__ unsigned long long* aux_keys() {
   __shared__ unsigned long long keys[RT_BLOCK];

@@ -21,11 +21,11 @@ using namespace rtd;
 namespace {
 
 #ifndef RT_QUEUE_CLASSES
-#define RT_QUEUE_CLASSES 8u  // tile queues per launch, a multiple of 8 (the XCDs)
+#define RT_QUEUE_CLASSES 16u  // tile queues per launch, a multiple of 8 (the XCDs): two per XCD (8 / 24 / 32 measured slower at three waves per SIMD)
 #endif
 #define RT_N_COUNTERS (64 + 8 * RT_QUEUE_CLASSES)  // u64 slots per counter block: 0-10 RtStats, 11-14 and 16-23 diagnostics, 24 reference rays, 64.. work queues
 #ifndef RT_BLOCKS_PER_CU
-#define RT_BLOCKS_PER_CU 4  // 256-thread blocks resident per CU at four waves per SIMD
+#define RT_BLOCKS_PER_CU 3  // 256-thread blocks resident per CU at three waves per SIMD
 #endif
 
 struct PartInfo {
@@ -81,7 +81,10 @@ __device__ __forceinline__ void flush_counters(const Counters& cn, unsigned long
 //   k_render_direct  direct integrator (color_at_direct), one lane per pixel, one wave per 8x8 tile, for group-less
 //                    worlds whose cost is the shadow-sample loop of an area light.
 #ifndef RT_WAVES_PER_EU
-#define RT_WAVES_PER_EU 4
+// Three waves per SIMD (168 VGPRs, no spills) since the auxiliary traversal became wave-cooperative: as fast as four
+// (128 VGPRs, ~58 spilled registers and 2 GB of scratch written per frame) on dragons and 5-30 % faster on the lighter
+// scenes.  Round 1's per-lane traversal needed the fourth wave to hide its fetch latency (5.6 vs 7.4 ms).
+#define RT_WAVES_PER_EU 3
 #endif
 #ifndef RT_CULL_MIN_SHAPES
 #define RT_CULL_MIN_SHAPES 6u
@@ -200,7 +203,10 @@ void k_render_jobs(Scene sc, RtCamera cam, RenderParams rp, PartInfo part, Pixel
 }
 // the direct integrator is force-inlined so that the register budget applies to it (as a called function it took 248
 // VGPRs whatever the kernel asked for: soft_shadows 4K 20.9 -> 12.4 ms at four waves per SIMD; 5: same, 6: slower)
-#define RT_DIRECT_ATTR __attribute__((amdgpu_waves_per_eu(RT_WAVES_PER_EU, RT_WAVES_PER_EU)))
+#ifndef RT_DIRECT_WAVES_PER_EU
+#define RT_DIRECT_WAVES_PER_EU 4
+#endif
+#define RT_DIRECT_ATTR __attribute__((amdgpu_waves_per_eu(RT_DIRECT_WAVES_PER_EU, RT_DIRECT_WAVES_PER_EU)))
 template <bool COUNT>
 __global__ __launch_bounds__(RT_BLOCK) RT_DIRECT_ATTR
 void k_render_direct(Scene sc, RtCamera cam, RenderParams rp, PartInfo part, PixelOut o, unsigned long long* counters) {
