@@ -306,8 +306,8 @@ int rt_canvas_to_u8_device(RtContext*, const RtCamera*, const RtRenderOptions*, 
  * Per-ray intersection lists.  The reference's list is unbounded (src/intersections.rs:66-73); the device keeps 96
  * entries per ray for the n1/n2 walk of a refracted hit (src/intersections.rs:141-160) and, for a ray that passes them,
  * continues in SIDE LISTS in device memory that belong to the context.  A context has none until one of its launches
- * overflows; then it allocates them (512 entries per ray and resident lane, 1.6 GB on an MI355X) and a further
- * overflow makes them four times as large, up to RT_SIDE_MAX entries (default 8192 = 26 GB; the environment variable
+ * overflows; then it allocates them (512 entries per ray and resident lane, 1.2 GB on an MI355X) and a further
+ * overflow makes them four times as large, up to RT_SIDE_MAX entries (default 8192 = 19 GB; the environment variable
  * RT_SIDE_MAX lowers or raises it).  While a context has side lists its launches run one after another and always
  * through the persistent kernel.
  *   - A synchronous call (stats != NULL, rt_render, rt_render_u8, rt_color_at) does this by itself: it grows the side

@@ -629,12 +629,12 @@ int take_sticky(RtContext* ctx, hipStream_t stream, unsigned long long* v) {
 #define RT_SIDE_FIRST 512u  // entries per list and lane of the first side-list allocation
 #endif
 #ifndef RT_SIDE_MAX
-#define RT_SIDE_MAX 8192u   // the largest: 12 B x 8192 x 262144 resident lanes = 26 GB of the 288
+#define RT_SIDE_MAX 8192u   // the largest: 12 B x 8192 x 196608 resident lanes = 19 GB of the 288
 #endif
 size_t side_lanes(const RtContext* ctx) { return (size_t)ctx->n_cus * RT_BLOCKS_PER_CU * RT_BLOCK; }
 // Gives the context side lists, or larger ones.  Synchronises the device: no launch may be using the old ones.
 int grow_side(RtContext* ctx) {
-  // RT_SIDE_MAX in the environment lowers (or raises) the limit: a host that would rather fail than give 26 GB away
+  // RT_SIDE_MAX in the environment lowers (or raises) the limit: a host that would rather fail than give 19 GB away
   uint32_t most = RT_SIDE_MAX;
   if (const char* e = std::getenv("RT_SIDE_MAX")) most = (uint32_t)std::strtoul(e, nullptr, 10);
   if (ctx->side_cap >= most)
