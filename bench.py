@@ -224,6 +224,7 @@ def main():
     # the same frame through rt_render: host buffers out (pageable memory), the PCIe-inclusive figure (never `value`)
     host_frame_ms = None
     host_frame_u8_ms = None
+    host_pinned_ms = None
     eighths_ms = None
     if world == 1 and rank == 0 and not args.no_extras:
         hbuf = np.empty((cam.vsize, cam.hsize, 3), dtype=np.float32)
@@ -243,6 +244,26 @@ def main():
                                    None), "rt_render_u8")
             ums.append((time.perf_counter() - th) * 1e3)
         host_frame_u8_ms = round(min(ums[1:]), 3)
+        # the same two calls into page-locked host buffers (rt_host_alloc): the copy is a DMA beside the next band
+        npx = cam.vsize * cam.hsize * 3
+        pf, pu = lib.rt_host_alloc(ctx, npx * 4), lib.rt_host_alloc(ctx, npx)
+        if pf and pu:
+            pms, qms = [], []
+            for _ in range(4):
+                th = time.perf_counter()
+                check(lib.rt_render(ctx, dscene, C.byref(rcam), C.byref(fopts), pf, None, None), "rt_render(pinned)")
+                pms.append((time.perf_counter() - th) * 1e3)
+            for _ in range(4):
+                th = time.perf_counter()
+                check(lib.rt_render_u8(ctx, dscene, C.byref(rcam), C.byref(fopts), abi.RT_DITHER_NONE, pu, None, None),
+                      "rt_render_u8(pinned)")
+                qms.append((time.perf_counter() - th) * 1e3)
+            host_pinned_ms = [round(min(pms[1:]), 3), round(min(qms[1:]), 3)]
+            pin_u8 = np.ctypeslib.as_array(C.cast(pu, C.POINTER(C.c_uint8)), shape=(npx,))
+            if not np.array_equal(pin_u8, ubuf.reshape(-1)):
+                raise RuntimeError("page-locked and pageable 8-bit frames differ")
+        lib.rt_host_free(ctx, pf)
+        lib.rt_host_free(ctx, pu)
         # strong-scaling preview: kernel time of each eighth of the frame (what each of 8 GPUs would render)
         eighths_ms = []
         for p in range(8):
@@ -282,6 +303,8 @@ def main():
                        # what the reference would cast: it re-traces secondary rays once per light
                        "rays_reference": int(ref_rays),
                        "frame_ms": round(ms_per_step, 3), "host_frame_ms": host_frame_ms, "host_frame_u8_ms": host_frame_u8_ms,
+                       "host_frame_pinned_ms": host_pinned_ms[0] if host_pinned_ms else None,
+                       "host_frame_u8_pinned_ms": host_pinned_ms[1] if host_pinned_ms else None,
                        "eighths_kernel_ms": eighths_ms, "scene_setup_s": round(setup_s, 2)},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }

@@ -293,6 +293,14 @@ int rt_render_u8(RtContext*, const RtDeviceScene*, const RtCamera*, const RtRend
 int rt_canvas_to_u8_device(RtContext*, const RtCamera*, const RtRenderOptions*, uint32_t dither, const float* d_rgb,
                            uint8_t* d_out_u8, void* stream);
 
+/* Page-locked host memory for the buffers handed to rt_render / rt_render_u8 / rt_color_at (optional: any host pointer
+ * works).  The copy of a frame into pageable memory runs at about 16 GB/s and keeps the calling thread busy; into
+ * memory from rt_host_alloc it is a DMA at the link's speed that overlaps the next band's kernel (4K frame as u8:
+ * 4.1 ms per call pageable, see DESIGN.md section 5 for the page-locked figure).  The reference's Canvas owns a Vec
+ * (src/canvas.rs:10-18); a host that wants this allocates the Vec's storage here instead.  Returns NULL on failure. */
+void* rt_host_alloc(RtContext*, uint64_t bytes);
+void rt_host_free(RtContext*, void* p);
+
 /* Same, but out_rgb / aux are DEVICE pointers on the context's GPU and nothing is copied back;
  * `stream` is a hipStream_t (NULL = the context's own stream, NOT the legacy null stream: a caller whose
  * other work is on the null stream, e.g. torch's default stream, must create a stream, pass it here and

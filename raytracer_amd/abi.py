@@ -98,7 +98,7 @@ AUX_TRI = np.dtype([("p1", "<f4", 3), ("shape", "<u4"), ("e1", "<f4", 3), ("owne
                     ("kind_flags", "<u4")])
 assert AUX_NODE.itemsize == 80 and AUX_TRI.itemsize == 48
 
-EXPORTS = ["rt_accel_build", "rt_accel_free", "rt_abi_version", "rt_context_create", "rt_context_destroy", "rt_last_error", "rt_scene_create",
+EXPORTS = ["rt_host_alloc", "rt_host_free", "rt_accel_build", "rt_accel_free", "rt_abi_version", "rt_context_create", "rt_context_destroy", "rt_last_error", "rt_scene_create",
            "rt_scene_destroy", "rt_part_rows", "rt_render", "rt_render_u8", "rt_canvas_to_u8_device", "rt_render_device", "rt_check", "rt_color_at", "rt_color_at_static"]
 
 
@@ -110,6 +110,8 @@ def declare(lib: C.CDLL) -> None:
     lib.rt_last_error.restype, lib.rt_last_error.argtypes = C.c_char_p, [P]
     lib.rt_scene_create.restype, lib.rt_scene_create.argtypes = C.c_int, [P, C.POINTER(RtScene), C.POINTER(P)]
     lib.rt_scene_destroy.restype, lib.rt_scene_destroy.argtypes = None, [P, P]
+    lib.rt_host_alloc.restype, lib.rt_host_alloc.argtypes = P, [P, C.c_uint64]
+    lib.rt_host_free.restype, lib.rt_host_free.argtypes = None, [P, P]
     lib.rt_accel_build.restype, lib.rt_accel_build.argtypes = C.c_int, [C.POINTER(RtScene), C.POINTER(RtAccelView)]
     lib.rt_accel_free.restype, lib.rt_accel_free.argtypes = None, [C.POINTER(RtAccelView)]
     lib.rt_part_rows.restype, lib.rt_part_rows.argtypes = C.c_uint32, [C.POINTER(RtCamera), C.POINTER(RtRenderOptions)]

@@ -1139,7 +1139,23 @@ static int render_host(RtContext* ctx, const RtDeviceScene* ds, const RtCamera* 
   int nb = 1;
   bands[0] = whole;
   if (whole.n_parts == 1 && cam->vsize >= 64) {
-    uint32_t bh = ((cam->vsize + RT_MAX_BANDS - 1) / RT_MAX_BANDS + 7u) & ~7u;
+    // Every extra launch has a tail of its own, every band's copy overlaps the next band's kernel: how many bands pay
+    // depends on how long the copy is.  Measured on dragons 4K (tools/gpu_bands.py, ms per call for 1/2/3/4 bands):
+    // f32 pageable 8.5/7.1/6.5/6.4, f32 page-locked 4.5/4.0/3.9/4.2, u8 pageable 4.1/3.8/3.9/4.1, u8 page-locked
+    // 3.1/3.3/3.5/3.9.
+    bool locked = false;
+    {
+      hipPointerAttribute_t at;
+      const void* dst = out_u8 && !out_rgb ? (const void*)out_u8 : (const void*)out_rgb;
+      if (hipPointerGetAttributes(&at, dst) == hipSuccess)
+        locked = at.type == hipMemoryTypeHost;
+      else
+        (void)hipGetLastError();  // an ordinary (pageable) pointer is "invalid" to the runtime
+    }
+    const bool bytes_only = out_u8 && !out_rgb;
+    uint32_t want = bytes_only ? (locked ? 1u : 2u) : (locked ? 2u : (uint32_t)RT_MAX_BANDS);
+    if (const char* e = std::getenv("RT_BANDS")) want = std::min<uint32_t>(RT_MAX_BANDS, std::max(1, std::atoi(e)));
+    uint32_t bh = ((cam->vsize + want - 1) / want + 7u) & ~7u;
     nb = (int)((cam->vsize + bh - 1) / bh);
     for (int b = 0; b < nb; b++)
       bands[b] = PartInfo{bh, (uint32_t)nb, (uint32_t)b, std::min(bh, cam->vsize - (uint32_t)b * bh)};
@@ -1195,6 +1211,23 @@ render_again:
   rc = settle_overflow(ctx, ctx->stream, local.overflow, true, &retry, &earlier);
   if (retry) goto render_again;  // the context has (larger) side lists now: the same frame again
   return rc;
+}
+
+void* rt_host_alloc(RtContext* ctx, uint64_t bytes) {
+  if (!ctx || bytes == 0) return nullptr;
+  if (hipSetDevice(ctx->device) != hipSuccess) return nullptr;
+  void* p = nullptr;
+  if (hipHostMalloc(&p, (size_t)bytes, hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    fail(ctx, RT_E_OOM, "rt_host_alloc: page-locked allocation of " + std::to_string(bytes) + " bytes failed");
+    return nullptr;
+  }
+  return p;
+}
+void rt_host_free(RtContext* ctx, void* p) {
+  if (!ctx || !p) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipHostFree(p);
 }
 
 int rt_render(RtContext* ctx, const RtDeviceScene* ds, const RtCamera* cam, const RtRenderOptions* opts,

@@ -369,6 +369,8 @@ extern "C" {
         d_out_u8: *mut u8,
         stream: *mut c_void,
     ) -> c_int;
+    pub fn rt_host_alloc(ctx: *mut RtContext, bytes: u64) -> *mut c_void;
+    pub fn rt_host_free(ctx: *mut RtContext, p: *mut c_void);
     pub fn rt_render_device(
         ctx: *mut RtContext,
         scene: *const RtDeviceScene,

@@ -83,3 +83,36 @@ def test_canvas_to_u8_device_special_values_and_parts():
     assert lib.rt_canvas_to_u8_device(ctx, C.byref(cam), None, 5, big_in.data_ptr() + 4, big_out.data_ptr() + 1, None) == abi.RT_OK
     assert lib.rt_check(ctx, None) == abi.RT_OK
     assert np.array_equal(big_out.cpu().numpy()[1: 1 + h * w * 3].reshape(h, w, 3), to_u8(rgb, 5))
+
+
+def test_page_locked_host_buffers_receive_the_same_frames():
+    """rt_host_alloc / rt_host_free (include/rt_abi.h): rt_render and rt_render_u8 into page-locked memory give the bytes
+    they give into pageable memory."""
+    import ctypes as C
+    from raytracer_amd import abi, host
+    from raytracer_amd.scene import Scene
+    from conftest import scene_path
+    lib = host.hip_lib()
+    scene = Scene.from_file(scene_path("basic_scene"))
+    hw = scene.build(host.new_world(0))
+    ctx, ds = hw.device_scene()
+    cam = scene.camera(320, 200)
+    rcam = hw.rt_camera(cam)
+    opts = abi.RtRenderOptions(abi.RT_JITTER_CONST, 0.5, 0, 1, 1, 0, 0)
+    n = 320 * 200 * 3
+    pf, pu = lib.rt_host_alloc(ctx, n * 4), lib.rt_host_alloc(ctx, n)
+    assert pf and pu
+    assert lib.rt_host_alloc(ctx, 0) is None
+    try:
+        f = np.zeros(n, dtype=np.float32)
+        u = np.zeros(n, dtype=np.uint8)
+        assert lib.rt_render(ctx, ds, C.byref(rcam), C.byref(opts), f.ctypes.data, None, None) == abi.RT_OK
+        assert lib.rt_render(ctx, ds, C.byref(rcam), C.byref(opts), pf, None, None) == abi.RT_OK
+        assert lib.rt_render_u8(ctx, ds, C.byref(rcam), C.byref(opts), abi.RT_DITHER_BAYER4, u.ctypes.data, None, None) == abi.RT_OK
+        assert lib.rt_render_u8(ctx, ds, C.byref(rcam), C.byref(opts), abi.RT_DITHER_BAYER4, pu, None, None) == abi.RT_OK
+        assert np.array_equal(np.ctypeslib.as_array(C.cast(pf, C.POINTER(C.c_float)), shape=(n,)).view(np.uint32), f.view(np.uint32))
+        assert np.array_equal(np.ctypeslib.as_array(C.cast(pu, C.POINTER(C.c_uint8)), shape=(n,)), u)
+        assert f.max() > 0.1 and u.max() > 0
+    finally:
+        lib.rt_host_free(ctx, pf)
+        lib.rt_host_free(ctx, pu)
