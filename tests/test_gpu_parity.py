@@ -682,3 +682,31 @@ def test_gather_pipeline_over_rccl(root):
                        text=True, timeout=240)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("frame ")]
     assert r.returncode == 0 and len(lines) == 5 and all("mismatching pixels 0," in ln for ln in lines), r.stdout + r.stderr[-2000:]
+
+
+def test_triangles_holding_a_nan_are_nobodys_duplicates():
+    """A shape that holds a NaN equals no shape, itself included (derived PartialEq over f32), so two smooth triangles
+    with the same corners and the same NaN normals are two different shapes: a ray that hits both at the same t reports
+    the FIRST (stable order of equal t), not "the last of its value-identical duplicates" that the device
+    reports for genuine duplicates (Q2).  Genuine duplicates next to them, for contrast."""
+    nan = float("nan")
+    tri = [-1, 0, 0, 1, 0, 0, 0, 1.5, 0]
+
+    def build(w):
+        g = w.group([("translate", 0, 0, 0.5)])
+        for _ in range(2):  # same corners, NaN normals: never equal
+            w.group_add_shape(g, w.shape("smooth-triangle", (), None, params=tri + [0, 0, -1, nan, 0, -1, 0, 0, -1]))
+        g2 = w.group([("translate", 3, 0, 0.5)])
+        for _ in range(2):  # genuine duplicates
+            w.group_add_shape(g2, w.shape("smooth-triangle", (), None, params=tri + [0, 0, -1, 0, 0, -1, 0, 0, -1]))
+        w.add_group(g)
+        w.add_group(g2)
+        w.add_point_light((0, 5, -10), (1, 1, 1))
+        return w
+
+    o = np.array([[0.0, 0.4, -5.0], [3.0, 0.4, -5.0], [0.3, 0.2, -5.0], [3.3, 0.2, -5.0]], dtype=np.float32)
+    d = np.tile(np.array([[0.0, 0.0, 1.0]], dtype=np.float32), (4, 1))
+    grgb, gt, gid, _ = build(host.new_world(0)).color_at(o, d, 2)
+    rrgb, rt_, rid, _ = build(_oracle().new_world()).color_at(o, d, 2)
+    assert np.array_equal(gid, rid) and np.array_equal(gt.view(np.uint32), rt_.view(np.uint32))
+    assert list(rid) == [0, 3, 0, 3]  # NaN pair: the first; genuine duplicates: the later one (Q2)
