@@ -1609,15 +1609,19 @@ __device__ __forceinline__ void pk_st3(const Park& pk, int k, V3 x) {
 // Persistent waves with a work queue: a wave draws its next items itself (one atomic per refill) instead of being
 // born for one tile, so heavy tiles do not leave CUs idle at the end of a frame and the grid is sized to the device,
 // not to the image.  Lanes that finish go idle; a wave takes a whole 8x8 tile (64 consecutive items) when all its lanes
-// are done.  Refilling partly idle waves was measured on dragons/cover at 4K: it keeps more lanes busy but mixes
-// pixels of different tiles in one wave, and the loss of coherence in the traversal costs more than the idle lanes did
-// (4.8 / 4.7 / 4.5 / 4.3 ms for a threshold of 1 / 8 / 32 / 64 idle lanes).
+// are done (RT_REFILL_MIN = 64).  Refilling partly idle waves keeps more lanes busy but mixes pixels of different tiles
+// in one wave, and the loss of coherence costs more than the idle lanes did -- measured twice: with round 1's
+// per-lane traversal (dragons 4K 4.8 / 4.7 / 4.5 / 4.3 ms for a threshold of 1 / 8 / 32 / 64 idle lanes) and with the
+// wave-cooperative one (2.87 / 2.80 / 2.80 / 2.70 / 2.51 ms for 8 / 16 / 32 / 48 / 64).
 // `Source` supplies the work: total(), start(item, ray) -> false if the item is outside the image, id(item) (the key
 // of the item's random numbers), first_hit(item, hit) and finish(item, colour, work).  `queue` is a zeroed counter in device memory.
 // Every wave leaves the loop: each refill advances the queue, and a wave whose lanes are all idle either refills
 // or, once the queue has run past total(), breaks.
 #define RT_QUEUE_STRIDE 8  // u64 slots between the queues of two classes (64 B: one atomic unit each)
 enum { ST_IDLE = 100 };
+#ifndef RT_REFILL_MIN
+#define RT_REFILL_MIN 64u
+#endif
 template <bool v, class A, class B>
 struct Pick {
   typedef A type;
@@ -1671,17 +1675,19 @@ __device__ inline void integrate(const Scene& sc, const RenderParams& rp, const 
     // on (every XCD has its own L2: a class is a fixed set of screen regions, so an XCD keeps meeting the same part of
     // the scene's trees) and moves on to the other classes' queues when its own is empty, so the split costs no balance.
     {
-      if (!exhausted && !wave_any(st != ST_IDLE)) {
+      // Lanes whose pixel is finished take new items once RT_REFILL_MIN of them are idle (64: a wave takes a whole 8x8
+      // tile when all its lanes are done).  The wave draws whole tiles from the queue into [chunk_next, chunk_end) and
+      // hands the items out to idle lanes from there, so a tile never spreads over two waves.
+      const unsigned long long idle_mask = __builtin_amdgcn_ballot_w64(st == ST_IDLE);
+      const uint32_t n_idle = (uint32_t)__builtin_popcountll(idle_mask);
+      if (n_idle >= RT_REFILL_MIN && (!exhausted || chunk_next < chunk_end)) {
         const uint32_t lane = threadIdx.x & 63u;
-        unsigned long long base = 0;
         // A draw takes rp.queue_chunk tiles with one atomic and the wave works through them: at one atomic per tile the
         // queue alone took 1.7 ms of a 4K frame (130 k tiles), the whole frame time of the simple scenes. Scenes with
         // heavy tiles keep a chunk of 1 (launch_part): there a run of neighbouring tiles in one wave cost more than
         // the atomics (dragons 4K 3.5 -> 4.5 ms).
-        if (chunk_next < chunk_end) {
-          base = chunk_next;
-          chunk_next += 64u;
-        } else {
+        if (chunk_next >= chunk_end) {
+          unsigned long long base = 0;
           const unsigned long long take = 64ull * rp.queue_chunk;
           while (true) {  // wave-uniform
             const unsigned long long size = src.class_items(q_class);
@@ -1689,7 +1695,7 @@ __device__ inline void integrate(const Scene& sc, const RenderParams& rp, const 
             base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) |
                    (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
             if (base < size) {
-              chunk_next = base + 64u;
+              chunk_next = base;
               chunk_end = base + take < size ? base + take : size;
               break;
             }
@@ -1700,11 +1706,15 @@ __device__ inline void integrate(const Scene& sc, const RenderParams& rp, const 
             }
           }
         }
-        if (!exhausted) {
-          const unsigned long long want = base + lane;
+        if (chunk_next < chunk_end) {
+          const unsigned long long avail = chunk_end - chunk_next;
+          const uint32_t n_take = avail < n_idle ? (uint32_t)avail : n_idle;
+          const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_mask, 0u));
+          const unsigned long long want = chunk_next + rank;
+          chunk_next += n_take;
           Ray primary;
           uint32_t it = 0;
-          if (want < src.class_items(q_class) && src.start(q_class, (uint32_t)want, it, primary)) {
+          if (st == ST_IDLE && rank < n_take && src.start(q_class, (uint32_t)want, it, primary)) {
             item = it;
             cn.primary++;
             if (COUNT) cn.ref_rays++;
@@ -1724,7 +1734,7 @@ __device__ inline void integrate(const Scene& sc, const RenderParams& rp, const 
         }
       }
       if (!wave_any(st != ST_IDLE)) {
-        if (exhausted) break;
+        if (exhausted && chunk_next >= chunk_end) break;
         continue;  // a draw that only held items outside the image: draw again
       }
     }
