@@ -143,6 +143,9 @@ struct PixelSource {
   // the last tiles should be cheap ones; with a camera above a floor looking slightly down (every sample scene of
   // the reference) the cheap tiles, sky, are at the top. Measured against top-down at 4K: dragons 3.55 -> 3.42 ms,
   // cover 3.58 -> 3.25 ms, dragons 1080p 1.60 -> 1.38 ms; a scene the other way round loses what these gain.
+  // Round 2 measured the alternatives again: top-down and middle-rows-outwards lose 4 % (dragons) and 10 % (cover), and
+  // the TRUE heaviest-first order -- supertiles sorted by the work the instrumented kernel counted in them -- is no
+  // better than bottom-up (dragons 2.53 vs 2.49 ms, cover 2.92 vs 2.90 ms): order has nothing left to give.
   __device__ uint32_t item_of(uint32_t c, uint32_t n) const {
     const uint32_t per = RT_SUPER * RT_SUPER * 64u;
     return ((n / per) * kClasses + c) * per + n % per;
@@ -150,7 +153,8 @@ struct PixelSource {
   __device__ void locate(uint32_t item, uint32_t& px, uint32_t& ly) const {
     const uint32_t w = item & 63u, tis = (item >> 6) & (RT_SUPER * RT_SUPER - 1u);
     const uint32_t L = super_x * super_y - 1u - (item >> (2u * RT_SUPER_LOG2 + 6u));
-    const uint32_t tx = (L % super_x) * RT_SUPER + (tis & (RT_SUPER - 1u)), ty = (L / super_x) * RT_SUPER + (RT_SUPER - 1u - tis / RT_SUPER);
+    const uint32_t srow = L / super_x, scol = L % super_x;
+    const uint32_t tx = scol * RT_SUPER + (tis & (RT_SUPER - 1u)), ty = srow * RT_SUPER + (RT_SUPER - 1u - tis / RT_SUPER);
     px = tx * 8u + (w & 7u);
     ly = ty * 8u + (w >> 3);
   }
@@ -192,12 +196,21 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAV
 void k_render_jobs(Scene sc, RtCamera cam, RenderParams rp, PartInfo part, PixelOut o, unsigned long long* counters) {
 #ifdef RT_PHASE_TIMERS
   const uint64_t t_pixel0 = __builtin_readcyclecounter();
+  const unsigned long long t_wall0 = wall_clock64();
 #endif
   PixelSource<COUNT> src{&sc, cam, part, o, (cam.hsize + 8u * RT_SUPER - 1u) / (8u * RT_SUPER), (part.rows + 8u * RT_SUPER - 1u) / (8u * RT_SUPER)};
   Counters cn = {};
   integrate<COUNT, CULL, SIDE>(sc, rp, src, sc.recursion_limit, counters + RT_QUEUE_SLOT, cn);
 #ifdef RT_PHASE_TIMERS
-  if ((threadIdx.x & 63) == 0) atomicAdd(counters + 14, (unsigned long long)(__builtin_readcyclecounter() - t_pixel0));
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(counters + 14, (unsigned long long)(__builtin_readcyclecounter() - t_pixel0));
+    // when the waves of the launch end (100 MHz wall clock): sum, latest, and earliest start as max of the complement
+    const unsigned long long t_end = wall_clock64();
+    atomicAdd(counters + 30, t_end);
+    atomicMax(counters + 31, t_end);
+    atomicMax(counters + 29, ~t_wall0);
+    atomicAdd(counters + 28, 1ull);
+  }
 #endif
   flush_counters(cn, counters, sc.sticky);
 }
@@ -591,6 +604,11 @@ int read_stats(RtContext* ctx, hipStream_t stream, RtStats* stats, double total_
     for (int k = 0; k < 4; k++)
       fprintf(stderr, "%s steps: lanes %llu waves %llu utilisation %.3f\n", nm[k], h[16 + 2 * k], h[17 + 2 * k],
               h[17 + 2 * k] ? (double)h[16 + 2 * k] / (64.0 * h[17 + 2 * k]) : 0.0);
+  }
+  if (h[28]) {
+    const double t0 = (double)(~h[29]), t_last = (double)h[31], t_mean = (double)h[30] / (double)h[28];
+    fprintf(stderr, "wave ends (100 MHz ticks): launch %.0f, mean end %.0f, last end %.0f => %.1f %% of wave-time idle at the end\n",
+            t_last - t0, t_mean - t0, t_last - t0, 100.0 * (t_last - t_mean) / (t_last - t0));
   }
   fprintf(stderr, "phase clocks (wave sums): pixel %llu  world_intersect %llu  aux %llu  shapes %llu  walk iterations %llu  node load %llu\n", h[14], h[11], h[12], h[13], h[15], h[10]);
 #endif
