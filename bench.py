@@ -265,11 +265,16 @@ def main():
         lib.rt_host_free(ctx, pf)
         lib.rt_host_free(ctx, pu)
         # strong-scaling preview: kernel time of each eighth of the frame (what each of 8 GPUs would render)
+        # (the host-frame measurements above leave the GPU idle during their copies: a few whole frames first, so that the
+        # parts are timed at the clocks a GPU that renders part after part runs at)
+        for _ in range(5):
+            check(lib.rt_render_device(ctx, dscene, C.byref(rcam), C.byref(opts), local.data_ptr(), None,
+                                       C.c_void_p(stream.cuda_stream), None), "rt_render_device(warm)")
         eighths_ms = []
         for p in range(8):
             po = abi.RtRenderOptions(abi.RT_JITTER_COUNTER, 0.5, 1, args.tile_h, 8, p, 0)
             best = 1e9
-            for _ in range(3):
+            for _ in range(5):
                 check(lib.rt_render_device(ctx, dscene, C.byref(rcam), C.byref(po), local.data_ptr(), None,
                                            C.c_void_p(stream.cuda_stream), C.byref(st)), "rt_render_device(part)")
                 best = min(best, st.kernel_ms)

@@ -258,7 +258,7 @@ void rt_scene_destroy(RtContext*, RtDeviceScene*);
  * reference: the acceleration data is private to this library; tests use this view to check it. */
 typedef struct {
   uint64_t n_nodes, n_tris, n_roots;
-  const void* nodes;       /* n_nodes x 80 B */
+  const void* nodes;       /* n_nodes x 128 B */
   const void* tris;        /* n_tris x 48 B */
   const uint32_t* root_of; /* per RtScene node: header index of the BVH covering its subtree, or 0xFFFFFFFF */
   const uint32_t* gate_next; /* per RtScene node inside a covered subtree: next group whose box test is not implied */

@@ -91,12 +91,14 @@ class RtAccelView(C.Structure):
                 ("tris", C.c_void_p), ("root_of", C.c_void_p), ("gate_next", C.c_void_p), ("owner", C.c_void_p)]
 
 
-AUX_NODE = np.dtype([("lmin", "<f4", 3), ("left", "<u4"), ("lmax", "<f4", 3), ("lcount", "<u4"),
-                     ("rmin", "<f4", 3), ("right", "<u4"), ("rmax", "<f4", 3), ("rcount", "<u4"),
-                     ("cone", "<f4", 4)])
+# 4-wide node (rt_accel.h Layout): eight {xyz, word}: b[2c] = min of child c, b[2c+1] = max of child c; words 0-3 the child
+# references (index << 4 | leaf triangle count, 0xFFFFFFFF = no such child), words 4-7 the normal cone as float bits.
+# An entry record uses b[0] = {centre, radius bits} and b[1] = {lmax, amax, top node as uint bits | first shape}.
+AUX_NODE = np.dtype([("v", "<f4", 3), ("w", "<u4")])
+AUX_NODE = np.dtype([("b", AUX_NODE, 8)])
 AUX_TRI = np.dtype([("p1", "<f4", 3), ("shape", "<u4"), ("e1", "<f4", 3), ("owner", "<u4"), ("e2", "<f4", 3),
                     ("kind_flags", "<u4")])
-assert AUX_NODE.itemsize == 80 and AUX_TRI.itemsize == 48
+assert AUX_NODE.itemsize == 128 and AUX_TRI.itemsize == 48
 
 EXPORTS = ["rt_host_alloc", "rt_host_free", "rt_accel_build", "rt_accel_free", "rt_abi_version", "rt_context_create", "rt_context_destroy", "rt_last_error", "rt_scene_create",
            "rt_scene_destroy", "rt_part_rows", "rt_render", "rt_render_u8", "rt_canvas_to_u8_device", "rt_render_device", "rt_check", "rt_color_at", "rt_color_at_static"]

@@ -19,17 +19,22 @@
 //      ancestor passes" (monotonicity of the correctly rounded slab arithmetic, for rays with at
 //      least one |d| >= 1e-4 component).  gate_next[] lists the groups whose test is NOT implied.
 //
-// Layout (device, 80 B per node, 16 B aligned):
+// Layout (device, 128 B per node, 16 B aligned): a 4-wide tree, made by folding every other level of the binary
+// SAH tree into its parent (a ray's traversal is a chain of dependent fetches, one per level: half the levels, half
+// the chain, and the per-step costs of the wave-cooperative traversal are paid half as often).
 //   aux[root]      entry record of one instance: {cx, cy, cz, radius} {lmax, amax, top node index, first shape}
 //                  (centre/radius of the padded boxes, longest edge, largest |e1|*|e2|)
-//   aux[top]       top node of the (possibly shared) tree; every node holds the boxes of BOTH children and its own normal cone:
-//     {lmin.xyz, left}  {lmax.xyz, lcount}  {rmin.xyz, right}  {rmax.xyz, rcount}  {a.xyz, cos w}
+//   aux[top]       top node of the (possibly shared) tree; every node holds the boxes of its 2-4 children and its own
+//                  normal cone, as eight float4:
+//     {min0.xyz, ref0} {max0.xyz, ref1} {min1.xyz, ref2} {max1.xyz, ref3}
+//     {min2.xyz, a.x}  {max2.xyz, a.y}  {min3.xyz, a.z}  {max3.xyz, cos w}
 //     cone: every triangle below the node has its unit normal within angle w of a/|a|, and
 //     1/sin(angle between its edges e1, e2) <= 1/|a|; cos w < -1 means "no bound".  The traversal turns
 //     that into a bound on K = |e1||e2||d|/|det| = 1/(sin(e1,e2) |cos(d, normal)|) for the node, which
 //     sets how far its child boxes must be widened for this ray (rule 1).
-//     count == 0: child is the node aux[left]; count > 0: child is the leaf
-//     aux_tris[left .. left+count), 3 float4 per triangle:
+//     ref = index << 4 | count.  count == 0: the child is the node aux[index]; count > 0: the child is the leaf
+//     aux_tris[index .. index+count); 0xFFFFFFFF: no such child (its box is empty: min = +inf, max = -inf).
+//     3 float4 per triangle:
 //       {p1.xyz, shape index - first shape of the instance} {e1.xyz, owning node index - root node}
 //       {e2.xyz, shape kind_flags}   (as uint bits)
 #pragma once
@@ -48,15 +53,15 @@ namespace rtaccel {
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr uint32_t kMinTris = 12;    // subtrees with fewer triangles keep the reference walk
 #ifndef RT_LEAF_TRIS
-#define RT_LEAF_TRIS 9
+#define RT_LEAF_TRIS 6
 #endif
 static_assert(RT_LEAF_TRIS >= 1 && RT_LEAF_TRIS <= 15, "leaf count is a 4-bit field");
 constexpr uint32_t kLeafTris = RT_LEAF_TRIS;    // max triangles per leaf
-constexpr int kMaxDepth = 20;        // device stack holds kMaxDepth + 2 entries (RT_AUX_STACK)
+constexpr int kMaxDepth = 20;        // of the binary tree: 10 levels when folded, 3 stack entries a level (RT_AUX_STACK 32)
 constexpr float kPadRel = 0.01f;     // static box padding relative to the triangle's largest extent
 constexpr float kPadAbs = 4e-6f;     // ... plus this times the largest |coordinate|
 
-struct Node {
+struct Node {  // node of the binary tree the builder makes; folded into Node4 for the device
   float lmin[3];
   uint32_t left;
   float lmax[3];
@@ -67,7 +72,16 @@ struct Node {
   uint32_t rcount;
   float cone[4];
 };
-static_assert(sizeof(Node) == 80, "aux node is 80 B");
+static_assert(sizeof(Node) == 80, "binary build node is 80 B");
+// the device node (see Layout): b[2c] = {min of child c, word}, b[2c+1] = {max of child c, word};
+// words 0-3: child references, words 4-7: the cone
+struct Node4 {
+  struct Q {
+    float v[3];
+    uint32_t w;
+  } b[8];
+};
+static_assert(sizeof(Node4) == 128, "aux node is 128 B");
 struct Tri {
   float p1[3];
   uint32_t shape;
@@ -79,7 +93,7 @@ struct Tri {
 static_assert(sizeof(Tri) == 48, "aux triangle is 48 B");
 
 struct Result {
-  std::vector<Node> nodes;         // all trees back to back
+  std::vector<Node4> nodes;        // all trees back to back, and the entry records
   std::vector<Tri> tris;           // leaf triangles in leaf order
   std::vector<uint32_t> root_of;   // per reference node: header index of the subtree's BVH (roots only) or kNone
   std::vector<uint32_t> gate_next; // per reference node inside a subtree: next group whose box test is not implied
@@ -391,7 +405,7 @@ inline Result build(const RtScene* s) {
   // Instancing: subtrees with the same triangles in the same arrangement (the reference re-parses and duplicates an
   // OBJ file for every instance, scene.rs:593-599) share one tree.  Leaf triangles hold the shape index relative to
   // the instance's first shape and the owning group relative to the instance's root; every root gets its own
-  // 80-B entry record {centre, radius}{lmax, amax, index of the tree's top node, first shape of the instance}.
+  // 128-B entry record {centre, radius}{lmax, amax, index of the tree's top node, first shape of the instance}.
   struct Inst {
     uint32_t n_items = 0, shape_base = 0;
     uint64_t hash = 0;
@@ -511,12 +525,48 @@ inline Result build(const RtScene* s) {
       continue;
     }
     outs[j].top = (uint32_t)nb;
-    for (size_t q = 1; q < outs[j].nodes.size(); q++) {  // local index q (header at 0) -> nb + q - 1
-      Node nd = outs[j].nodes[q];
-      nd.left = (uint32_t)(nd.lcount ? tbase + nd.left : nb + nd.left - 1);
-      nd.right = (uint32_t)(nd.rcount ? tbase + nd.right : nb + nd.right - 1);
-      r.nodes.push_back(nd);
-    }
+    // fold the binary tree (local indices, header at 0, top at 1) into 4-wide nodes, parents before children
+    const std::vector<Node>& bn = outs[j].nodes;
+    struct Fold {
+      const std::vector<Node>& bn;
+      std::vector<Node4>& out;
+      uint64_t tbase;
+      uint32_t emit(uint32_t q) {
+        const uint32_t me = (uint32_t)out.size();
+        out.emplace_back();
+        struct Child {
+          const float *mn, *mx;
+          uint32_t ref, count;
+        } ch[4];
+        int n = 0;
+        const Node& N = bn[q];
+        auto side = [&](const float* mn, const float* mx, uint32_t ref, uint32_t count) {
+          if (count == 0) {  // an inner child: its two children take its place
+            const Node& C = bn[ref];
+            ch[n++] = Child{C.lmin, C.lmax, C.left, C.lcount};
+            ch[n++] = Child{C.rmin, C.rmax, C.right, C.rcount};
+          } else {
+            ch[n++] = Child{mn, mx, ref, count};
+          }
+        };
+        side(N.lmin, N.lmax, N.left, N.lcount);
+        side(N.rmin, N.rmax, N.right, N.rcount);
+        Node4 nd;
+        for (int c = 0; c < 4; c++) {
+          for (int a = 0; a < 3; a++) {
+            nd.b[2 * c].v[a] = c < n ? ch[c].mn[a] : INFINITY;
+            nd.b[2 * c + 1].v[a] = c < n ? ch[c].mx[a] : -INFINITY;
+          }
+          uint32_t ref = kNone;
+          if (c < n) ref = ch[c].count ? (uint32_t)(((tbase + ch[c].ref) << 4) | ch[c].count) : (emit(ch[c].ref) << 4);
+          nd.b[c].w = ref;
+          std::memcpy(&nd.b[4 + c].w, &N.cone[c], 4);
+        }
+        out[me] = nd;
+        return me;
+      }
+    } fold{bn, r.nodes, tbase};
+    fold.emit(1);
     for (Tri t : outs[j].tris) {
       t.shape -= inst[j].shape_base;
       t.owner -= roots[j];
@@ -528,9 +578,13 @@ inline Result build(const RtScene* s) {
     const Out& o = outs[inst[j].same_as];
     if (!o.ok) continue;
     uint32_t R = roots[j];
-    Node h = o.nodes[0];
-    std::memcpy(&h.lmax[2], &o.top, 4);
-    h.lcount = inst[j].shape_base;
+    const Node& h2 = o.nodes[0];  // {centre, radius}{lmax, amax, .., ..} from TreeBuilder::finish
+    Node4 h{};
+    std::memcpy(h.b[0].v, h2.lmin, 12);
+    h.b[0].w = h2.left;
+    h.b[1].v[0] = h2.lmax[0], h.b[1].v[1] = h2.lmax[1];
+    std::memcpy(&h.b[1].v[2], &o.top, 4);
+    h.b[1].w = inst[j].shape_base;
     r.root_of[R] = (uint32_t)r.nodes.size();
     r.nodes.push_back(h);
     // gate chains: gate_next[c] = nearest proper ancestor A below R whose test is not implied by the

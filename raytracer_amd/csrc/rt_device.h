@@ -20,7 +20,7 @@
 #ifndef RT_XS_CAP
 #define RT_XS_CAP 96         // per-ray entries for the n1/n2 container walk
 #endif
-#define RT_AUX_STACK 22      // per-lane auxiliary-BVH stack entries, kept in LDS (rt_accel.h kMaxDepth + 2)
+#define RT_AUX_STACK 32      // per-lane auxiliary-BVH stack entries, kept in LDS (rt_accel.h: 3 per level of the 4-wide tree, kMaxDepth / 2 levels, + 2)
 #ifndef RT_BLOCK
 #define RT_BLOCK 256         // threads per block of every kernel that traces (LDS stack stride): 256 or 64
 #endif
@@ -732,6 +732,70 @@ __device__ __forceinline__ bool aux_box(V3 o, V3 inv, float pad, f4n mn, f4n mx,
   tnear = tn;
   return !(tn > tf) && !(tn > hi) && !(tf < lo);
 }
+// One visit of a 4-wide node (rt_accel.h Layout): the boxes of its 2-4 children, widened for this ray by the node's
+// normal-cone bound (see aux_intersect), against the t range [lo0, lim].  Returns the nearest child that is hit and
+// pushes the others onto the lane's stack, farthest first; RT_AUX_NONE when none is hit.
+//   K = |e1||e2||d| / |det| <= kmax for every accepted hit; the cone gives the usually far smaller bound
+//   K <= 1 / (sin(e1,e2) * |cos(d, normal)|): |cos(d, normal)| >= cos(phi + w) for every triangle below, phi = angle(d, axis)
+template <bool COUNT>
+__device__ __forceinline__ uint32_t aux_node4(const Scene& sc, const uint32_t idx, const V3 o, const V3 inv, const V3 dn,
+                                              const float kmax, const float padk, const float inv_dm, const bool use_cone,
+                                              const float lo0, const float lim, uint32_t* stk, int& sp, Counters& cn) {
+  const f4n RT_CONST_AS* N = cst(reinterpret_cast<const f4n*>(sc.aux_nodes)) + 8u * (size_t)idx;
+  const f4n q0 = N[0], q1 = N[1], q2 = N[2], q3 = N[3], q4 = N[4], q5 = N[5], q6 = N[6], q7 = N[7];
+  RT_UTIL(0);
+  uint32_t r0 = __float_as_uint(q0.w), r1 = __float_as_uint(q1.w), r2 = __float_as_uint(q2.w), r3 = __float_as_uint(q3.w);
+  if (COUNT) cn.aux_tests += 2u + (r2 != RT_AUX_NONE) + (r3 != RT_AUX_NONE);
+  float kb = kmax;
+  if (use_cone && q7.w >= -1.f) {
+    const float ik2 = q4.w * q4.w + q5.w * q5.w + q6.w * q6.w;               // (1 / max(1/sin(e1,e2)))^2
+    const float cp = __builtin_fabsf(dn.x * q4.w + dn.y * q5.w + dn.z * q6.w);  // cos(phi) / kalpha
+    const float sw = __builtin_amdgcn_sqrtf(__builtin_fmaxf(0.f, 1.f - q7.w * q7.w));
+    const float q = cp * q7.w - __builtin_amdgcn_sqrtf(__builtin_fmaxf(0.f, ik2 - cp * cp)) * sw;  // cos(phi+w) / kalpha
+    // rounding (worst where ik2 - cp^2 cancels) moves q by < 4e-4 / kalpha: under 4 % of a q that passes
+    if (q > 0.f && q * q > 1e-4f * ik2) kb = __builtin_fminf(kmax, __builtin_amdgcn_rcpf(q) * 1.06f);
+  }
+  const float pad = padk * kb;
+  const float tpad = pad * inv_dm;
+  const float lo = lo0 - tpad;
+  const float hi = (lim + 1e-5f * __builtin_fabsf(lim)) + tpad;
+  float t0, t1, t2, t3;
+  const bool h0 = aux_box(o, inv, pad, q0, q1, lo, hi, t0);
+  const bool h1 = aux_box(o, inv, pad, q2, q3, lo, hi, t1);
+  const bool h2 = aux_box(o, inv, pad, q4, q5, lo, hi, t2) && r2 != RT_AUX_NONE;
+  const bool h3 = aux_box(o, inv, pad, q6, q7, lo, hi, t3) && r3 != RT_AUX_NONE;
+  const float inf = __builtin_inff();
+  if (!h0) r0 = RT_AUX_NONE, t0 = inf;
+  if (!h1) r1 = RT_AUX_NONE, t1 = inf;
+  if (!h2) r2 = RT_AUX_NONE, t2 = inf;
+  if (!h3) r3 = RT_AUX_NONE, t3 = inf;
+  // nearest first (the order only decides how soon the search narrows): a five-exchange network
+#define RT_CSWAP(ta, ra, tb, rb)        \
+  {                                     \
+    const bool sw_ = tb < ta;           \
+    const float tt_ = sw_ ? tb : ta;    \
+    const uint32_t rr_ = sw_ ? rb : ra; \
+    tb = sw_ ? ta : tb;                 \
+    rb = sw_ ? ra : rb;                 \
+    ta = tt_;                           \
+    ra = rr_;                           \
+  }
+  RT_CSWAP(t0, r0, t1, r1)
+  RT_CSWAP(t2, r2, t3, r3)
+  RT_CSWAP(t0, r0, t2, r2)
+  RT_CSWAP(t1, r1, t3, r3)
+  RT_CSWAP(t1, r1, t2, r2)
+#undef RT_CSWAP
+  const int n_push = (r1 != RT_AUX_NONE) + (r2 != RT_AUX_NONE) + (r3 != RT_AUX_NONE);
+  if (sp + n_push <= RT_AUX_STACK) {
+    if (r3 != RT_AUX_NONE) stk[(sp++) * RT_BLOCK] = r3;
+    if (r2 != RT_AUX_NONE) stk[(sp++) * RT_BLOCK] = r2;
+    if (r1 != RT_AUX_NONE) stk[(sp++) * RT_BLOCK] = r1;
+  } else {
+    cn.overflow++;
+  }
+  return r0;
+}
 // Would the reference have reached the shapes of group `g` from the subtree root `root`?  The box test
 // of g, then of every group on the way up whose test is not implied by nesting (rt_accel.h gate_next).
 template <bool COUNT>
@@ -755,7 +819,7 @@ __device__ inline bool aux_intersect(const Scene& sc, uint32_t root_node, uint32
   // the nesting argument behind aux_gate needs one axis on the non-parallel branch of check_axis
   if (!(__builtin_fabsf(cur.d.x) >= 1e-4f || __builtin_fabsf(cur.d.y) >= 1e-4f || __builtin_fabsf(cur.d.z) >= 1e-4f))
     return false;
-  const f4n RT_CONST_AS* A = cst(reinterpret_cast<const f4n*>(sc.aux_nodes)) + 5u * (size_t)aux_root;
+  const f4n RT_CONST_AS* A = cst(reinterpret_cast<const f4n*>(sc.aux_nodes)) + 8u * (size_t)aux_root;
   f4n h0 = A[0], h1 = A[1];
   // Ray-dependent widening (DESIGN.md "Auxiliary BVH"): in f32 the reference's triangle test accepts a
   // line that passes the triangle's plane up to 16u * K * (|s| + L) outside it (u = 2^-24,
@@ -790,52 +854,9 @@ __device__ inline bool aux_intersect(const Scene& sc, uint32_t root_node, uint32
   while (true) {
     uint32_t cnt = ref & 15u, idx = ref >> 4;  // reference = index << 4 | leaf triangle count (0: inner node)
     if (cnt == 0u) {
-      const f4n RT_CONST_AS* N = cst(reinterpret_cast<const f4n*>(sc.aux_nodes)) + 5u * (size_t)idx;
-      f4n n0 = N[0], n1 = N[1], n2 = N[2], n3 = N[3];
-      RT_UTIL(0);
-      if (COUNT) cn.aux_tests += 2;
-      float kb = kmax;
-      f4n n4 = f4n{0.f, 0.f, 0.f, -2.f};
-      if (use_cone) n4 = N[4];
-#ifndef RT_CONE_MODE
-#define RT_CONE_MODE 2
-#endif
-#if RT_CONE_MODE == 0
-      if (n4.w > 3.f) kb = 0.f;
-#else
-#if RT_CONE_MODE == 1
-#define RT_SQRT __builtin_sqrtf
-#else
-#define RT_SQRT __builtin_amdgcn_sqrtf
-#endif
-      if (n4.w >= -1.f) {  // cone: |cos(d, normal)| >= cos(phi + w) for every triangle below, phi = angle(d, axis)
-        float ik2 = n4.x * n4.x + n4.y * n4.y + n4.z * n4.z;                  // (1 / max(1/sin(e1,e2)))^2
-        float cp = __builtin_fabsf(dn.x * n4.x + dn.y * n4.y + dn.z * n4.z);  // cos(phi) / kalpha
-        float sw = RT_SQRT(__builtin_fmaxf(0.f, 1.f - n4.w * n4.w));
-        float q = cp * n4.w - RT_SQRT(__builtin_fmaxf(0.f, ik2 - cp * cp)) * sw;  // cos(phi+w) / kalpha
-        // rounding (worst where ik2 - cp^2 cancels) moves q by < 4e-4 / kalpha: under 4 % of a q that passes
-        if (q > 0.f && q * q > 1e-4f * ik2) kb = __builtin_fminf(kmax, __builtin_amdgcn_rcpf(q) * 1.06f);
-      }
-#endif
-      const float pad = padk * kb;
-      const float tpad = pad * inv_dm;
-      const float lo = lo0 - tpad;
-      float lim = sink.limit();
-      float hi = (lim + 1e-5f * __builtin_fabsf(lim)) + tpad;
-      float tl, tr;
-      bool hl = aux_box(cur.o, inv, pad, n0, n1, lo, hi, tl);
-      bool hr = aux_box(cur.o, inv, pad, n2, n3, lo, hi, tr);
-      uint32_t rl = (__float_as_uint(n0.w) << 4) | __float_as_uint(n1.w);
-      uint32_t rr = (__float_as_uint(n2.w) << 4) | __float_as_uint(n3.w);
-      if (hl && hr) {
-        bool left_first = !(tr < tl);
-        ref = left_first ? rl : rr;
-        if (sp < RT_AUX_STACK) stk[(sp++) * RT_BLOCK] = left_first ? rr : rl;
-        else cn.overflow++;
-        continue;
-      }
-      if (hl || hr) {
-        ref = hl ? rl : rr;
+      const uint32_t next = aux_node4<COUNT>(sc, idx, cur.o, inv, dn, kmax, padk, inv_dm, use_cone, lo0, sink.limit(), stk, sp, cn);
+      if (next != RT_AUX_NONE) {
+        ref = next;
         continue;
       }
     } else {
@@ -874,7 +895,8 @@ __device__ inline bool aux_intersect(const Scene& sc, uint32_t root_node, uint32
 // The winner's (u, v) are not carried: the shading step recomputes them for smooth triangles (same arithmetic).
 // ---------------------------------------------------------------------------------------
 #ifndef RT_STEAL_MIN_IDLE
-#define RT_STEAL_MIN_IDLE 16  // lanes without work before the wave looks for work to hand out
+#define RT_STEAL_MIN_IDLE 8   // lanes without work before the wave looks for work to hand out (4-wide tree: 8 and 6-triangle
+                             // leaves measured best, dragons 4K 2.44 -> 2.39 ms; 16 and 9 were best on the binary tree)
 #endif
 #ifndef RT_STEAL_PERIOD
 #define RT_STEAL_PERIOD 1     // ... every this many steps
@@ -885,6 +907,7 @@ __device__ inline bool aux_intersect(const Scene& sc, uint32_t root_node, uint32
 #ifndef RT_LEAF_BATCH
 #define RT_LEAF_BATCH 40      // lanes waiting at a leaf that start a leaf step while others could still descend
 #endif
+__device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 __device__ __forceinline__ unsigned long long* aux_keys() {
   __shared__ unsigned long long keys[RT_BLOCK];
   return keys;
@@ -898,176 +921,169 @@ __device__ __forceinline__ float pull_f(int lane, float v) {
 __device__ __forceinline__ uint32_t pull_u(int lane, uint32_t v) {
   return (uint32_t)__builtin_amdgcn_ds_bpermute(lane << 2, (int)v);
 }
+// What a lane traverses, and for whom: the ray in tree space, its pruning bounds, the search mode and the owner lane.
+struct CoopTask {
+  Ray T;
+  float Tpadk, Tbound;
+  int Tmode;
+  uint32_t Towner;
+  // derived from the ray (see aux_intersect for the bounds behind the numbers); recomputed when the task changes hands
+  float Tkmax, inv_dm;
+  V3 dn, inv;
+  bool use_cone;
+  __device__ __forceinline__ void derive(float h1x, float h1y) {
+    const float dm = magnitude(T.d);
+    Tkmax = 1e4f * h1y * dm;  // (the owner's expression on the owner's values: the same bits wherever it is computed)
+    inv_dm = __builtin_amdgcn_rcpf(dm) * 1.000001f;
+    dn = inv_dm * T.d;  // feeds the cone bound only (6 % slack there): no need for three IEEE divisions
+    use_cone = Tpadk * Tkmax > RT_CONE_MIN_PAD * h1x;
+    inv = v3(__builtin_amdgcn_rcpf(T.d.x), __builtin_amdgcn_rcpf(T.d.y), __builtin_amdgcn_rcpf(T.d.z));
+  }
+};
+// One step of a lane's traversal: a node (both child boxes) or a leaf (its triangles), then the next reference from
+// the lane's stack rows [bot, sp), or `work` = false.
+template <bool COUNT>
+__device__ __forceinline__ void coop_step(const Scene& sc, Counters& cn, const CoopTask& K, const uint32_t shape_base,
+                                          const uint32_t root_node, unsigned long long* keys, uint32_t* stk, uint32_t& ref,
+                                          int& sp, const int bot, bool& work) {
+  const unsigned long long kcur = __hip_atomic_load(&keys[K.Towner], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  // nothing at or beyond lim can matter: the owner's best so far, capped by its bound (shadow: the light);
+  // key 0 = a shadow search that has its occluder
+  const float lim = kcur == 0ull ? -__builtin_inff() : __builtin_fminf(__uint_as_float((uint32_t)(kcur >> 32)), K.Tbound);
+  uint32_t next = RT_AUX_NONE;
+  const uint32_t cnt = ref & 15u, idx = ref >> 4;
+  if (kcur == 0ull) {
+    sp = bot;  // drop what is left
+  } else if (cnt == 0u) {
+    // closest / shadow searches never want t <= 0
+    next = aux_node4<COUNT>(sc, idx, K.T.o, K.inv, K.dn, K.Tkmax, K.Tpadk, K.inv_dm, K.use_cone, 0.f, lim, stk, sp, cn);
+  } else {
+    if (COUNT) cn.tri_tests += cnt;
+    RT_UTIL(1);
+    const f4n RT_CONST_AS* Tr = cst(reinterpret_cast<const f4n*>(sc.aux_tris)) + 3u * (size_t)idx;
+    for (uint32_t k = 0; k < cnt; k++) {
+      f4n a = Tr[3 * k], b = Tr[3 * k + 1], c = Tr[3 * k + 2];
+      const uint32_t kf = __float_as_uint(c.w);
+      const bool takes = (kf & RT_SHAPE_SHADOW) ? K.Tmode != SINK_CLOSEST_NOSHADOW : K.Tmode != SINK_ANY_SHADOW;
+      float t, u, v;
+      if (takes && isect_triangle(K.T, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), v3(c.x, c.y, c.z), t, u, v)) {
+        const uint32_t shape = shape_base + __float_as_uint(a.w);
+        const unsigned long long kc = hit_key(t, (int)shape);
+        const unsigned long long kn = __hip_atomic_load(&keys[K.Towner], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // Sink::wants: positive, in front of the bound, before the best so far in (t, rank) order
+        if (t > 0.f && !(t >= K.Tbound) && kc < kn && aux_gate<COUNT>(sc, root_node + __float_as_uint(b.w), root_node, K.T, cn))
+          __hip_atomic_fetch_min(&keys[K.Towner], K.Tmode == SINK_ANY_SHADOW ? 0ull : kc, __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+  }
+  if (next == RT_AUX_NONE) {
+    if (sp > bot)
+      next = stk[(--sp) * RT_BLOCK];
+    else
+      work = false;
+  }
+  ref = next;
+}
+// Which lanes step now: lanes that have reached a leaf wait while others still descend, until enough of them are
+// there.  A leaf step is a serial loop over up to RT_LEAF_TRIS triangles, and run for a few lanes at a time (every
+// iteration, as lanes happen to arrive) it dominated the cost (16 % of the lanes active in it).
+__device__ __forceinline__ bool coop_steps_now(bool work, uint32_t ref) {
+  const bool at_leaf = work && (ref & 15u) != 0u;
+  const unsigned long long leaf_lanes = __builtin_amdgcn_ballot_w64(at_leaf);
+  const bool leaf_phase = (uint32_t)__builtin_popcountll(leaf_lanes) >= RT_LEAF_BATCH ||
+                          leaf_lanes == __builtin_amdgcn_ballot_w64(work);
+  return work && at_leaf == leaf_phase;
+}
+// Hand deferred subtrees to lanes of the wave without work.  Pairing: the r-th idle lane takes from the r-th donor.
+// Ranks come from the ballot masks (mbcnt); the donors' lane numbers are compacted to the low lanes with one
+// ds_permute (every lane pushes its number: donors to their rank, the others to the remaining slots from the top, a
+// bijection), and a thief pulls its victim's number from the lane of its own rank.  (A serial loop over pairs cost ~4
+// vector instructions per pair.)  Returns true for a lane that has just taken a task.
+__device__ __forceinline__ bool coop_steal(const unsigned long long busy, const uint32_t n_idle, CoopTask& K, uint32_t* stk,
+                                           uint32_t& ref, int& sp, int& bot, bool& work) {
+  const uint32_t lane = threadIdx.x & 63u;
+  unsigned long long donors = __builtin_amdgcn_ballot_w64(work && sp > bot);
+  if (donors == 0ull) return false;
+  const unsigned long long idle = ~busy;
+  const uint32_t n_donors = (uint32_t)__builtin_popcountll(donors);
+  const uint32_t rd = __builtin_amdgcn_mbcnt_hi((uint32_t)(donors >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)donors, 0u));
+  const uint32_t ri = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+  const bool is_donor = ((donors >> lane) & 1ull) != 0ull;
+  const uint32_t dest = is_donor ? rd : 63u - (lane - rd);
+  const uint32_t compact = (uint32_t)__builtin_amdgcn_ds_permute((int)(dest << 2), (int)lane);
+  const uint32_t donor_of_rank = pull_u((int)(ri & 63u), compact);
+  const bool steals = !work && ri < n_donors;
+  const int victim = steals ? (int)donor_of_rank : -1;  // thief: the lane it takes from
+  const bool gives = is_donor && rd < n_idle;           // donor: its bottom entry goes to a thief
+  uint32_t entry = 0u;
+  if (gives) {
+    entry = stk[bot * RT_BLOCK];
+    bot++;
+  }
+  // thieves pull the task from their victim's registers (every lane executes the pulls; a lane without a victim
+  // reads its own)
+  const int src = victim >= 0 ? victim : (int)lane;
+  const uint32_t e = pull_u(src, entry);
+  const float ox = pull_f(src, K.T.o.x), oy = pull_f(src, K.T.o.y), oz = pull_f(src, K.T.o.z);
+  const float dx = pull_f(src, K.T.d.x), dy = pull_f(src, K.T.d.y), dz = pull_f(src, K.T.d.z);
+  const float pk = pull_f(src, K.Tpadk), bd = pull_f(src, K.Tbound);
+  const uint32_t om = pull_u(src, K.Towner | ((uint32_t)K.Tmode << 16));  // owner (< RT_BLOCK) and mode in one word
+  if (victim >= 0) {
+    K.T = Ray{v3(ox, oy, oz), v3(dx, dy, dz)};
+    K.Tpadk = pk;
+    K.Tbound = bd;
+    K.Towner = om & 0xFFFFu;
+    K.Tmode = (int)(om >> 16);
+    ref = e;
+    sp = bot = 0;
+    work = true;
+    return true;
+  }
+  return false;
+}
+
 // want: this lane's ray reached the subtree root (wave-uniform root_node / aux_root).  handled (for lanes that want):
 // false = this ray must take the reference walk through the subtree.  Every lane of the wave must call.
 template <bool COUNT, class Sink>
 __device__ inline void aux_coop(const Scene& sc, const uint32_t root_node, const uint32_t aux_root, const Ray& cur, Sink& sink,
                                 Counters& cn, const bool want, bool& handled) {
-  const f4n RT_CONST_AS* A = cst(reinterpret_cast<const f4n*>(sc.aux_nodes)) + 5u * (size_t)aux_root;
+  const f4n RT_CONST_AS* A = cst(reinterpret_cast<const f4n*>(sc.aux_nodes)) + 8u * (size_t)aux_root;
   const f4n h0 = A[0], h1 = A[1];
-  // ---- the task of this lane's own ray (see aux_intersect for the bounds behind the numbers) ----
-  Ray T = cur;
-  float Tkmax, Tpadk;
-  // values derived from the task's ray; recomputed after a steal
-  float dm, inv_dm, lo0;
-  V3 dn, inv;
-  bool use_cone;
-  auto derive = [&]() {
-    dm = magnitude(T.d);
-    Tkmax = 1e4f * h1.y * dm;
-    inv_dm = __builtin_amdgcn_rcpf(dm) * 1.000001f;
-    dn = inv_dm * T.d;  // feeds the cone bound only (6 % slack there): no need for three IEEE divisions
-    use_cone = Tpadk * Tkmax > RT_CONE_MIN_PAD * h1.x;
-    inv = v3(__builtin_amdgcn_rcpf(T.d.x), __builtin_amdgcn_rcpf(T.d.y), __builtin_amdgcn_rcpf(T.d.z));
-    lo0 = 0.f;  // closest / shadow searches never want t <= 0
-  };
+  // ---- the task of this lane's own ray ----
+  CoopTask K;
+  K.T = cur;
   bool work;
   {
     const bool axis_ok = __builtin_fabsf(cur.d.x) >= 1e-4f || __builtin_fabsf(cur.d.y) >= 1e-4f || __builtin_fabsf(cur.d.z) >= 1e-4f;
     const V3 oc = cur.o - v3(h0.x, h0.y, h0.z);
     const float S = magnitude(oc) + h0.w;
-    Tpadk = 1.43e-6f * (S + h1.x);
-    derive();
-    work = want && axis_ok && (Tpadk * Tkmax < __builtin_inff());
+    K.Tpadk = 1.43e-6f * (S + h1.x);
+    K.derive(h1.x, h1.y);
+    work = want && axis_ok && (K.Tpadk * K.Tkmax < __builtin_inff());
   }
   handled = work;
-  float Tbound = sink.bound;
-  int Tmode = sink.mode;
-  uint32_t Towner = threadIdx.x;
+  K.Tbound = sink.bound;
+  K.Tmode = sink.mode;
+  K.Towner = threadIdx.x;
   const uint32_t shape_base = __float_as_uint(h1.w);
   unsigned long long* keys = aux_keys();
   const unsigned long long key0 = hit_key(sink.t, sink.shape);
-  if (work) __hip_atomic_store(&keys[Towner], key0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  if (work) __hip_atomic_store(&keys[K.Towner], key0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   uint32_t* stk = aux_stack();
   int sp = 0, bot = 0;  // deferred subtrees of this lane: rows [bot, sp) of its column
   uint32_t ref = __float_as_uint(h1.z) << 4;
   uint32_t iter = 0;
-  const uint32_t lane = threadIdx.x & 63u;
   while (true) {
-    // One kind of step per iteration.  Lanes that have reached a leaf wait while others still descend, until enough of
-    // them are there: a leaf step is a serial loop over up to RT_LEAF_TRIS triangles, and run for a few lanes at a time
-    // (every iteration, as lanes happen to arrive) it dominated the cost (16 % of the lanes active in it).
-    const bool at_leaf = work && (ref & 15u) != 0u;
-    const unsigned long long leaf_lanes = __builtin_amdgcn_ballot_w64(at_leaf);
-    const bool leaf_phase = (uint32_t)__builtin_popcountll(leaf_lanes) >= RT_LEAF_BATCH ||
-                            leaf_lanes == __builtin_amdgcn_ballot_w64(work);
-    if (work && at_leaf == leaf_phase) {
-      const unsigned long long kcur = __hip_atomic_load(&keys[Towner], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      // nothing at or beyond lim can matter: the owner's best so far, capped by its bound (shadow: the light);
-      // key 0 = a shadow search that has its occluder
-      const float lim = kcur == 0ull ? -__builtin_inff() : __builtin_fminf(__uint_as_float((uint32_t)(kcur >> 32)), Tbound);
-      uint32_t next = RT_AUX_NONE;
-      const uint32_t cnt = ref & 15u, idx = ref >> 4;
-      if (kcur == 0ull) {
-        sp = bot;  // drop what is left
-      } else if (cnt == 0u) {
-        const f4n RT_CONST_AS* N = cst(reinterpret_cast<const f4n*>(sc.aux_nodes)) + 5u * (size_t)idx;
-        f4n n0 = N[0], n1 = N[1], n2 = N[2], n3 = N[3];
-        RT_UTIL(0);
-        if (COUNT) cn.aux_tests += 2;
-        float kb = Tkmax;
-        f4n n4 = f4n{0.f, 0.f, 0.f, -2.f};
-        if (use_cone) n4 = N[4];
-        if (n4.w >= -1.f) {  // normal cone, see aux_intersect
-          float ik2 = n4.x * n4.x + n4.y * n4.y + n4.z * n4.z;
-          float cp = __builtin_fabsf(dn.x * n4.x + dn.y * n4.y + dn.z * n4.z);
-          float sw = __builtin_amdgcn_sqrtf(__builtin_fmaxf(0.f, 1.f - n4.w * n4.w));
-          float q = cp * n4.w - __builtin_amdgcn_sqrtf(__builtin_fmaxf(0.f, ik2 - cp * cp)) * sw;
-          if (q > 0.f && q * q > 1e-4f * ik2) kb = __builtin_fminf(Tkmax, __builtin_amdgcn_rcpf(q) * 1.06f);
-        }
-        const float pad = Tpadk * kb;
-        const float tpad = pad * inv_dm;
-        const float lo = lo0 - tpad;
-        const float hi = (lim + 1e-5f * __builtin_fabsf(lim)) + tpad;
-        float tl, tr;
-        const bool hl = aux_box(T.o, inv, pad, n0, n1, lo, hi, tl);
-        const bool hr = aux_box(T.o, inv, pad, n2, n3, lo, hi, tr);
-        const uint32_t rl = (__float_as_uint(n0.w) << 4) | __float_as_uint(n1.w);
-        const uint32_t rr = (__float_as_uint(n2.w) << 4) | __float_as_uint(n3.w);
-        if (hl && hr) {
-          const bool left_first = !(tr < tl);
-          next = left_first ? rl : rr;
-          if (sp < RT_AUX_STACK) stk[(sp++) * RT_BLOCK] = left_first ? rr : rl;
-          else cn.overflow++;
-        } else if (hl || hr) {
-          next = hl ? rl : rr;
-        }
-      } else {
-        if (COUNT) cn.tri_tests += cnt;
-        RT_UTIL(1);
-        const f4n RT_CONST_AS* Tr = cst(reinterpret_cast<const f4n*>(sc.aux_tris)) + 3u * (size_t)idx;
-        for (uint32_t k = 0; k < cnt; k++) {
-          f4n a = Tr[3 * k], b = Tr[3 * k + 1], c = Tr[3 * k + 2];
-          const uint32_t kf = __float_as_uint(c.w);
-          const bool takes = (kf & RT_SHAPE_SHADOW) ? Tmode != SINK_CLOSEST_NOSHADOW : Tmode != SINK_ANY_SHADOW;
-          float t, u, v;
-          if (takes && isect_triangle(T, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), v3(c.x, c.y, c.z), t, u, v)) {
-            const uint32_t shape = shape_base + __float_as_uint(a.w);
-            const unsigned long long kc = hit_key(t, (int)shape);
-            const unsigned long long kn = __hip_atomic_load(&keys[Towner], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            // Sink::wants: positive, in front of the bound, before the best so far in (t, rank) order
-            if (t > 0.f && !(t >= Tbound) && kc < kn && aux_gate<COUNT>(sc, root_node + __float_as_uint(b.w), root_node, T, cn))
-              __hip_atomic_fetch_min(&keys[Towner], Tmode == SINK_ANY_SHADOW ? 0ull : kc, __ATOMIC_RELAXED,
-                                     __HIP_MEMORY_SCOPE_WORKGROUP);
-          }
-        }
-      }
-      if (next == RT_AUX_NONE) {
-        if (sp > bot)
-          next = stk[(--sp) * RT_BLOCK];
-        else
-          work = false;
-      }
-      ref = next;
-    }
+    // one kind of step per iteration (coop_steps_now)
+    if (coop_steps_now(work, ref)) coop_step<COUNT>(sc, cn, K, shape_base, root_node, keys, stk, ref, sp, bot, work);
     const unsigned long long busy = __builtin_amdgcn_ballot_w64(work);
     if (busy == 0ull) break;
     // ---- hand deferred subtrees to lanes without work ----
     iter++;
     const uint32_t n_idle = 64u - (uint32_t)__builtin_popcountll(busy);
     if (n_idle >= RT_STEAL_MIN_IDLE && (iter % RT_STEAL_PERIOD) == 0u) {
-      unsigned long long donors = __builtin_amdgcn_ballot_w64(work && sp > bot);
-      if (donors != 0ull) {
-        // Pairing: the r-th idle lane takes from the r-th donor.  Ranks come from the ballot masks (mbcnt); the donors'
-        // lane numbers are compacted to the low lanes with one ds_permute (every lane pushes its number: donors to
-        // their rank, the others to the remaining slots from the top, a bijection), and a thief pulls its victim's
-        // number from the lane of its own rank.  (A serial loop over pairs cost ~4 vector instructions per pair.)
-        const unsigned long long idle = ~busy;
-        const uint32_t n_donors = (uint32_t)__builtin_popcountll(donors);
-        const uint32_t rd = __builtin_amdgcn_mbcnt_hi((uint32_t)(donors >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)donors, 0u));
-        const uint32_t ri = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
-        const bool is_donor = ((donors >> lane) & 1ull) != 0ull;
-        const uint32_t dest = is_donor ? rd : 63u - (lane - rd);
-        const uint32_t compact = (uint32_t)__builtin_amdgcn_ds_permute((int)(dest << 2), (int)lane);
-        const uint32_t donor_of_rank = pull_u((int)(ri & 63u), compact);
-        const bool steals = !work && ri < n_donors;
-        const int victim = steals ? (int)donor_of_rank : -1;  // thief: the lane it takes from
-        const bool gives = is_donor && rd < n_idle;           // donor: its bottom entry goes to a thief
-        uint32_t entry = 0u;
-        if (gives) {
-          entry = stk[bot * RT_BLOCK];
-          bot++;
-        }
-        // thieves pull the task from their victim's registers (every lane executes the pulls; a lane without a victim
-        // reads its own)
-        const int src = victim >= 0 ? victim : (int)lane;
-        const uint32_t e = pull_u(src, entry);
-        const float ox = pull_f(src, T.o.x), oy = pull_f(src, T.o.y), oz = pull_f(src, T.o.z);
-        const float dx = pull_f(src, T.d.x), dy = pull_f(src, T.d.y), dz = pull_f(src, T.d.z);
-        const float pk = pull_f(src, Tpadk), bd = pull_f(src, Tbound);
-        const uint32_t om = pull_u(src, Towner | ((uint32_t)Tmode << 16));  // owner (< RT_BLOCK) and mode in one word
-        if (victim >= 0) {
-          T = Ray{v3(ox, oy, oz), v3(dx, dy, dz)};
-          Tpadk = pk;
-          Tbound = bd;
-          Towner = om & 0xFFFFu;
-          Tmode = (int)(om >> 16);
-          derive();  // (Tkmax too: the owner's expression on the owner's values, the same bits, one pull less)
-          ref = e;
-          sp = bot = 0;
-          work = true;
-        }
-      }
+      if (coop_steal(busy, n_idle, K, stk, ref, sp, bot, work)) K.derive(h1.x, h1.y);
     }
   }
   // ---- the owner takes its result ----
@@ -1116,7 +1132,6 @@ __device__ inline Ray ray_in_space_of(const Scene& sc, int xf_node, const Ray& w
 // node is the one it is waiting for.  After node i, a visiting lane waits for i+1 or for skip(i); lanes
 // that sat the visit out wait for something >= skip(i); so the next uniform index is i+1 if any lane
 // descends and skip(i) otherwise.
-__device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 #ifndef RT_WI_INLINE
 #define RT_WI_INLINE inline
 #endif
@@ -1617,6 +1632,7 @@ __device__ __forceinline__ void pk_st3(const Park& pk, int k, V3 x) {
 // of the item's random numbers), first_hit(item, hit) and finish(item, colour, work).  `queue` is a zeroed counter in device memory.
 // Every wave leaves the loop: each refill advances the queue, and a wave whose lanes are all idle either refills
 // or, once the queue has run past total(), breaks.
+#define RT_QUEUE_SLOT_OFFSET 64  // the counter block starts this many slots before `queue` (RT_QUEUE_SLOT)
 #define RT_QUEUE_STRIDE 8  // u64 slots between the queues of two classes (64 B: one atomic unit each)
 enum { ST_IDLE = 100 };
 #ifndef RT_REFILL_MIN
@@ -1651,6 +1667,9 @@ __device__ inline void integrate(const Scene& sc, const RenderParams& rp, const 
                          : 0u;
   uint32_t q_tried = 0;
   uint32_t item = 0, work_start = 0;
+#ifdef RT_PHASE_TIMERS
+  unsigned long long tile_t0 = 0ull, tile_first = 0ull;
+#endif
 
   // the hit being shaded: with the parked ray, enough to rebuild what Computations::prepare holds
   uint32_t remaining = 0u, path = 1u;
@@ -1680,6 +1699,15 @@ __device__ inline void integrate(const Scene& sc, const RenderParams& rp, const 
       // hands the items out to idle lanes from there, so a tile never spreads over two waves.
       const unsigned long long idle_mask = __builtin_amdgcn_ballot_w64(st == ST_IDLE);
       const uint32_t n_idle = (uint32_t)__builtin_popcountll(idle_mask);
+#ifdef RT_PHASE_TIMERS
+      // how long the wave's last draw of items took (100 MHz ticks): histogram over log2 in slots 32.., the longest in 60
+      if (n_idle == 64u && tile_t0 != 0ull && (threadIdx.x & 63u) == 0u) {
+        const unsigned long long dur = wall_clock64() - tile_t0;
+        atomicAdd(queue - RT_QUEUE_SLOT_OFFSET + 32 + (dur ? 63 - __builtin_clzll(dur) : 0), 1ull);
+        atomicMax(queue - RT_QUEUE_SLOT_OFFSET + 60, (dur << 32) | (tile_first & 0xFFFFFFFFull));
+        tile_t0 = 0ull;
+      }
+#endif
       if (n_idle >= RT_REFILL_MIN && (!exhausted || chunk_next < chunk_end)) {
         const uint32_t lane = threadIdx.x & 63u;
         // A draw takes rp.queue_chunk tiles with one atomic and the wave works through them: at one atomic per tile the
@@ -1711,6 +1739,10 @@ __device__ inline void integrate(const Scene& sc, const RenderParams& rp, const 
           const uint32_t n_take = avail < n_idle ? (uint32_t)avail : n_idle;
           const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_mask, 0u));
           const unsigned long long want = chunk_next + rank;
+#ifdef RT_PHASE_TIMERS
+          tile_t0 = wall_clock64();
+          tile_first = src.item_of(q_class, (uint32_t)chunk_next);
+#endif
           chunk_next += n_take;
           Ray primary;
           uint32_t it = 0;

@@ -277,6 +277,7 @@ struct RaySource {
   static constexpr uint32_t kClasses = 1u;
   RayOut o;
   __device__ unsigned long long class_items(uint32_t) const { return o.n; }
+  __device__ uint32_t item_of(uint32_t, uint32_t n) const { return n; }
   __device__ bool start(uint32_t, uint32_t i, uint32_t& item, Ray& r) const {
     item = i;
     r = Ray{v3(o.origins[3 * i], o.origins[3 * i + 1], o.origins[3 * i + 2]),
@@ -610,6 +611,12 @@ int read_stats(RtContext* ctx, hipStream_t stream, RtStats* stats, double total_
     fprintf(stderr, "wave ends (100 MHz ticks): launch %.0f, mean end %.0f, last end %.0f => %.1f %% of wave-time idle at the end\n",
             t_last - t0, t_mean - t0, t_last - t0, 100.0 * (t_last - t_mean) / (t_last - t0));
   }
+  {
+    fprintf(stderr, "draws by duration (log2 of 10 ns ticks: count):");
+    for (int k = 0; k < 28; k++)
+      if (h[32 + k]) fprintf(stderr, " %d:%llu", k, h[32 + k]);
+    fprintf(stderr, "; longest %.1f us, first item %llu\n", (double)(h[60] >> 32) * 0.01, h[60] & 0xFFFFFFFFull);
+  }
   fprintf(stderr, "phase clocks (wave sums): pixel %llu  world_intersect %llu  aux %llu  shapes %llu  walk iterations %llu  node load %llu\n", h[14], h[11], h[12], h[13], h[15], h[10]);
 #endif
   stats->kernel_ms = ms;
@@ -920,7 +927,7 @@ int rt_scene_create(RtContext* ctx, const RtScene* s, RtDeviceScene** out) {
     const float* dnc = nullptr;
     UP(dnc, nc.recs.data(), nc.recs.size())
     d.node_cull = reinterpret_cast<const float4*>(dnc);
-    const rtaccel::Node* an = nullptr;
+    const rtaccel::Node4* an = nullptr;
     const rtaccel::Tri* at = nullptr;
     UP(d.nodes, nodes.data(), nodes.size())
     UP(an, acc.nodes.data(), acc.nodes.size())

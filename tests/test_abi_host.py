@@ -142,19 +142,25 @@ def test_aux_bvh_is_well_formed(obj_files):
         sub = np.arange(R, end)
         assert np.all(nodes["xform"][R + 1:end] == 0), "only the subtree root may carry a transform"
         n_tris = int(nodes["n_shapes"][sub].sum())
-        hdr = an[roots[R]]  # entry record of this instance: {centre, radius}{lmax, amax, top node, first shape}
-        radius = hdr["left"].view(np.float32)
-        top, shape_base = int(hdr["lmax"][2:3].view(np.uint32)[0]), int(hdr["lcount"])
+        hdr = an[roots[R]]["b"]  # entry record of this instance: {centre, radius}{lmax, amax, top node, first shape}
+        centre, radius = hdr["v"][0], hdr["w"][0:1].view(np.float32)[0]
+        top, shape_base = int(hdr["v"][1][2:3].view(np.uint32)[0]), int(hdr["w"][1])
         tops.add(top)
         stack = [(top, 0, np.full(3, -np.inf), np.full(3, np.inf))]
         depth_max, seen = 0, 0
         while stack:
             idx, depth, lo, hi = stack.pop()
             depth_max = max(depth_max, depth)
-            nd = an[idx]
-            for side in ("l", "r"):
-                mn, mx = nd[side + "min"], nd[side + "max"]
-                ref, cnt = int(nd["left" if side == "l" else "right"]), int(nd[side + "count"])
+            nd = an[idx]["b"]  # a 4-wide node: 2 to 4 children, the missing ones with an empty box
+            present = [c for c in range(4) if int(nd["w"][c]) != NONE]
+            assert present == list(range(len(present))) and len(present) >= 2, "children fill the node from the front"
+            for c in range(4):
+                mn, mx = nd["v"][2 * c], nd["v"][2 * c + 1]
+                word = int(nd["w"][c])
+                if word == NONE:
+                    assert np.all(mn == np.inf) and np.all(mx == -np.inf)
+                    continue
+                ref, cnt = word >> 4, word & 15
                 assert np.all(mn >= lo) and np.all(mx <= hi), "child box sticks out of its parent"
                 if cnt == 0:
                     stack.append((ref, depth + 1, mn, mx))
@@ -170,8 +176,8 @@ def test_aux_bvh_is_well_formed(obj_files):
                         np.array_equal(t["e2"], g["e2"])
                     for v in (g["p1"], g["p1"] + g["e1"], g["p1"] + g["e2"]):
                         assert np.all(v >= mn) and np.all(v <= mx), "leaf box does not hold its triangle"
-                        assert np.linalg.norm(v - hdr["lmin"]) <= radius
-        assert seen == n_tris and depth_max <= 22
+                        assert np.linalg.norm(v - centre) <= radius
+        assert seen == n_tris and depth_max <= 10  # three stack entries a level: RT_AUX_STACK 32
         # gate chains: walking gate_next from any group reaches the root through ancestors only, and every
         # ancestor that is skipped contains the box below it
         for g0 in sub[1::7]:

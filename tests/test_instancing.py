@@ -92,7 +92,7 @@ def test_six_dragons_hold_one_copy_of_the_triangles():
     # and the library recognises the six subtrees as one tree (shared auxiliary BVH)
     acc = abi.accel_arrays(host.hip_lib(), fs)
     roots = acc["root_of"][acc["root_of"] != 0xFFFFFFFF]
-    tops = {int(acc["nodes"][r]["lmax"][2].view(np.uint32)) for r in roots}
+    tops = {int(acc["nodes"][r]["b"]["v"][1][2:3].view(np.uint32)[0]) for r in roots}  # entry record: b[1] = {lmax, amax, top, base}
     assert len(roots) == 6 and len(tops) == 1
 
 
