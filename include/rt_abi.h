@@ -37,7 +37,7 @@ extern "C" {
 
 enum {
   RT_OK = 0,
-  RT_E_ABI = -1,     /* version/size mismatch, NULL argument */
+  RT_E_ABI = -1,     /* version/size mismatch, NULL argument, empty camera, frame beyond 65535 pixels a side */
   RT_E_DEVICE = -2,  /* HIP error */
   RT_E_OOM = -3,     /* device allocation failed */
   RT_E_SCENE = -4,   /* scene violates a device limit (chain depth, csg depth, ...) */

@@ -161,34 +161,30 @@ struct PixelSource {
   __device__ uint32_t global_row(uint32_t ly) const {
     return (ly / part.tile_h) * (part.n_parts * part.tile_h) + part.part * part.tile_h + (ly % part.tile_h);
   }
+  // The token a lane keeps for its pixel is (row in the part << 16 | column): locate() divides by the supertile count,
+  // ~40 instructions, and finish / first_hit / id would each pay it again (rt_scene limits: frames below 65536 x 65536).
   __device__ bool start(uint32_t c, uint32_t n, uint32_t& item, Ray& r) const {
-    item = item_of(c, n);
     uint32_t px, ly;
-    locate(item, px, ly);
+    locate(item_of(c, n), px, ly);
+    item = (ly << 16) | px;
     if (px >= cam.hsize || ly >= part.rows) return false;
     r = ray_for_pixel(cam, px, global_row(ly));
     return true;
   }
   __device__ uint32_t id(uint32_t item) const {  // absolute pixel: the same random numbers whatever the partition
-    uint32_t px, ly;
-    locate(item, px, ly);
-    return global_row(ly) * cam.hsize + px;
+    return global_row(item >> 16) * cam.hsize + (item & 0xFFFFu);
   }
   __device__ void first_hit(uint32_t item, const Hit& ph) const {
-    uint32_t px, ly;
-    locate(item, px, ly);
-    write_hit(o, (size_t)ly * cam.hsize + px, ph);
+    write_hit(o, (size_t)(item >> 16) * cam.hsize + (item & 0xFFFFu), ph);
   }
   __device__ void finish(uint32_t item, V3 col, uint32_t work, Counters& cn) const {
-    uint32_t px, ly;
-    locate(item, px, ly);
     float ws = 0.f, wc = 0.f;
     if (COUNT) {  // per-pixel shares for the work map
       ws = (float)cn.work_shadow, wc = (float)cn.work_collect;
       cn.work_shadow = 0;
       cn.work_collect = 0;
     }
-    write_colour<COUNT>(*sc, o, (size_t)ly * cam.hsize + px, col, (float)work, ws, wc);
+    write_colour<COUNT>(*sc, o, (size_t)(item >> 16) * cam.hsize + (item & 0xFFFFu), col, (float)work, ws, wc);
   }
 };
 template <bool COUNT, bool CULL, bool SIDE = false>
@@ -1029,6 +1025,8 @@ static int launch_part(RtContext* ctx, const Scene& sc, const RtCamera* cam, con
     // item ids run over whole 128x128 supertiles (PixelSource) and must fit 32 bits
     const uint64_t super_items = (uint64_t)((cam->hsize + 8u * RT_SUPER - 1u) / (8u * RT_SUPER)) * ((part.rows + 8u * RT_SUPER - 1u) / (8u * RT_SUPER)) * (RT_SUPER * RT_SUPER * 64u);
     if (super_items >= 0xFFFFFFFFull) return fail(ctx, RT_E_ABI, "image too large");
+    // ... and a lane keeps its pixel as (row << 16 | column) (PixelSource::start)
+    if (cam->hsize > 0xFFFFu || part.rows > 0xFFFFu) return fail(ctx, RT_E_ABI, "image too large (65535 pixels a side)");
     const uint32_t blocks = (uint32_t)std::min<uint64_t>((items + RT_BLOCK - 1) / RT_BLOCK, (uint64_t)ctx->n_cus * RT_BLOCKS_PER_CU);
     const bool cull = (sc.props & RT_SCENE_SHAPE_CULL) != 0;  // the scene has cull records (rt_scene_create)
     auto kern = count ? (cull ? k_render_jobs<true, true> : k_render_jobs<true, false>)

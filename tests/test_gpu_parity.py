@@ -610,6 +610,10 @@ def test_abi_error_paths():
     # empty camera
     cam0 = abi.RtCamera(0, 16, 0.01, 1, 1)
     assert lib.rt_render_device(raw.ctx, raw.ds, C.byref(cam0), None, out.data_ptr(), None, None, None) == abi.RT_E_ABI
+    # a frame wider than a lane's pixel token (row << 16 | column) is refused before anything is launched or written
+    wide = abi.RtCamera(70000, 16, 0.01, 1, 1)
+    assert lib.rt_render_device(raw.ctx, raw.ds, C.byref(wide), None, out.data_ptr(), None, None, None) == abi.RT_E_ABI
+    assert b"too large" in lib.rt_last_error(raw.ctx)
     # a scene with an out-of-range index is rejected before anything reaches the GPU
     fs = raw.hw.flatten()
     arr = abi.scene_arrays(fs)
