@@ -79,7 +79,8 @@ struct Counters {
   // the primary stands for n_lights^k reference rays.  Equal to primary+shadow+reflect+refract with one light.
   uint32_t ref_rays;
 #ifdef RT_PHASE_TIMERS
-  uint32_t t_iters, t_load;
+  uint32_t t_iters, t_load;            // walk iterations, clocks waiting for node records
+  uint32_t t_jobs, t_refill, t_draw;   // job-loop iterations, clocks in the refill and in its queue draw
   uint32_t u[8];  // lane / wave step counts: aux node, aux leaf, walk visit, walk shapes
   uint32_t t_world, t_aux, t_shapes;   // diagnostics build: wave clock spent in world_intersect / aux BVH / shape tests
 #endif
@@ -1690,6 +1691,10 @@ __device__ inline void integrate(const Scene& sc, const RenderParams& rp, const 
   int st = ST_IDLE;
   while (true) {
     // ---------------- refill: a wave whose lanes are all idle takes the next tile(s) ----------------
+    RT_T0(trf);
+#ifdef RT_PHASE_TIMERS
+    cn.t_jobs++;
+#endif
     // The work is split into Source::kClasses classes, one queue each.  A wave draws from the class of the XCD it runs
     // on (every XCD has its own L2: a class is a fixed set of screen regions, so an XCD keeps meeting the same part of
     // the scene's trees) and moves on to the other classes' queues when its own is empty, so the split costs no balance.
@@ -1714,6 +1719,7 @@ __device__ inline void integrate(const Scene& sc, const RenderParams& rp, const 
         // queue alone took 1.7 ms of a 4K frame (130 k tiles), the whole frame time of the simple scenes. Scenes with
         // heavy tiles keep a chunk of 1 (launch_part): there a run of neighbouring tiles in one wave cost more than
         // the atomics (dragons 4K 3.5 -> 4.5 ms).
+        RT_T0(tdr);
         if (chunk_next >= chunk_end) {
           unsigned long long base = 0;
           const unsigned long long take = 64ull * rp.queue_chunk;
@@ -1734,6 +1740,7 @@ __device__ inline void integrate(const Scene& sc, const RenderParams& rp, const 
             }
           }
         }
+        RT_TACC(t_draw, tdr);
         if (chunk_next < chunk_end) {
           const unsigned long long avail = chunk_end - chunk_next;
           const uint32_t n_take = avail < n_idle ? (uint32_t)avail : n_idle;
@@ -1770,6 +1777,7 @@ __device__ inline void integrate(const Scene& sc, const RenderParams& rp, const 
         continue;  // a draw that only held items outside the image: draw again
       }
     }
+    RT_TACC(t_refill, trf);
     const bool active = st != ST_IDLE;
     // ---------------- the one traversal ----------------
     SinkT<List> sink;

@@ -23,7 +23,7 @@ namespace {
 #ifndef RT_QUEUE_CLASSES
 #define RT_QUEUE_CLASSES 16u  // tile queues per launch, a multiple of 8 (the XCDs): two per XCD (8 / 24 / 32 measured slower at three waves per SIMD)
 #endif
-#define RT_N_COUNTERS (64 + 8 * RT_QUEUE_CLASSES)  // u64 slots per counter block: 0-10 RtStats, 11-14 and 16-23 diagnostics, 24 reference rays, 64.. work queues
+#define RT_N_COUNTERS (64 + 8 * RT_QUEUE_CLASSES)  // u64 slots per counter block: 0-10 RtStats, 11-23 and 25-60 diagnostics (RT_PHASE_TIMERS), 24 reference rays, 64.. work queues
 #ifndef RT_BLOCKS_PER_CU
 #define RT_BLOCKS_PER_CU 3  // 256-thread blocks resident per CU at three waves per SIMD
 #endif
@@ -54,6 +54,10 @@ __device__ __forceinline__ void flush_counters(const Counters& cn, unsigned long
     atomicAdd(g + 12, (unsigned long long)cn.t_aux);
     atomicAdd(g + 13, (unsigned long long)cn.t_shapes);
     atomicAdd(g + 10, (unsigned long long)cn.t_load);  // slot of aux_tests: meaningful in non-COUNT runs only
+    atomicAdd(g + 15, (unsigned long long)cn.t_jobs);
+    atomicAdd(g + 25, (unsigned long long)cn.t_refill);
+    atomicAdd(g + 26, (unsigned long long)cn.t_iters);
+    atomicAdd(g + 27, (unsigned long long)cn.t_draw);
 #endif
     if (w0) atomicAdd(g + 5, (unsigned long long)w0);
     if (w1) atomicAdd(g + 6, (unsigned long long)w1);
@@ -613,7 +617,7 @@ int read_stats(RtContext* ctx, hipStream_t stream, RtStats* stats, double total_
       if (h[32 + k]) fprintf(stderr, " %d:%llu", k, h[32 + k]);
     fprintf(stderr, "; longest %.1f us, first item %llu\n", (double)(h[60] >> 32) * 0.01, h[60] & 0xFFFFFFFFull);
   }
-  fprintf(stderr, "phase clocks (wave sums): pixel %llu  world_intersect %llu  aux %llu  shapes %llu  walk iterations %llu  node load %llu\n", h[14], h[11], h[12], h[13], h[15], h[10]);
+  fprintf(stderr, "phase clocks (wave sums): pixel %llu  world_intersect %llu  aux %llu  shapes %llu  refill %llu (queue draw %llu)  node load %llu; job-loop iterations %llu, walk iterations %llu\n", h[14], h[11], h[12], h[13], h[25], h[27], h[10], h[15], h[26]);
 #endif
   stats->kernel_ms = ms;
   stats->total_ms = total_ms;
