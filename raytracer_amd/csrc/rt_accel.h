@@ -42,6 +42,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 #include <vector>
@@ -401,6 +402,33 @@ inline Result build(const RtScene* s) {
     const RtNode& n = s->nodes[i];
     bool inside_parent = n.parent >= 0 && sub_ok[n.parent] && n.xform == 0;
     if (sub_ok[i] && !inside_parent) roots.push_back(i);
+  }
+  // A subtree with more triangles than a tree of kMaxDepth levels can hold (the builder falls back to median splits
+  // where SAH would go deeper, so the count alone decides: 6 * 2^19 = 3.1 M) is covered piecewise: its child groups
+  // become roots of their own, and its own shapes keep the reference's linear tests.  RT_AUX_MAX_TRIS in the
+  // environment lowers the limit (tests).
+  {
+    uint64_t max_tris = ~0ull;
+    if (const char* e = std::getenv("RT_AUX_MAX_TRIS")) max_tris = std::strtoull(e, nullptr, 10);
+    std::vector<uint64_t> below(nn, 0);  // triangles in the subtree of node i
+    for (uint32_t i = nn; i-- > 0;) {
+      below[i] += s->nodes[i].n_shapes;
+      if (s->nodes[i].parent >= 0) below[(uint32_t)s->nodes[i].parent] += below[i];
+    }
+    std::vector<uint32_t> fit;
+    while (!roots.empty()) {
+      const uint32_t R = roots.back();
+      roots.pop_back();
+      const uint64_t n = below[R];
+      const bool too_big = n > max_tris || n > 0xFFFFFFF0ull || 1 + TreeBuilder::levels_for((uint32_t)n) > kMaxDepth;
+      if (!too_big) {
+        fit.push_back(R);
+        continue;
+      }
+      for (uint32_t c = R + 1; c < s->nodes[R].skip; c = s->nodes[c].skip) roots.push_back(c);  // direct children
+    }
+    std::sort(fit.begin(), fit.end());
+    roots.swap(fit);
   }
   // Instancing: subtrees with the same triangles in the same arrangement (the reference re-parses and duplicates an
   // OBJ file for every instance, scene.rs:593-599) share one tree.  Leaf triangles hold the shape index relative to

@@ -129,10 +129,31 @@ def test_aux_bvh_is_well_formed(obj_files):
     scene, hw, fs = _flat("small_dragons")
     a = abi.scene_arrays(fs)
     acc = abi.accel_arrays(host.hip_lib(), fs)
+    has = _check_aux(a, acc)
+    assert len(has) == 6  # dragons.yaml: six dragon.obj instances, each one covered subtree
+
+
+def test_oversized_subtrees_are_covered_piecewise(monkeypatch):
+    """A subtree with more triangles than one auxiliary tree can hold (3.1 M; RT_AUX_MAX_TRIS lowers the limit for
+    this test) is split: its child groups become roots of their own, its own shapes keep the reference's tests."""
+    scene, hw, fs = _flat("small_dragons")
+    a = abi.scene_arrays(fs)
+    whole = abi.accel_arrays(host.hip_lib(), fs)
+    n_whole = len(whole["tris"])
+    monkeypatch.setenv("RT_AUX_MAX_TRIS", "600")
+    acc = abi.accel_arrays(host.hip_lib(), fs)
+    has = _check_aux(a, acc, one_tree=False)
+    nodes = a["nodes"]
+    assert len(has) > 6
+    below = [int(nodes["n_shapes"][int(R):int(nodes["skip"][R])].sum()) for R in has]
+    assert max(below) <= 600
+    assert 0 < len(acc["tris"]) < n_whole  # (shared between the six instances) the split groups' own triangles are left out
+
+
+def _check_aux(a, acc, one_tree=True):
     nodes, shapes, roots, gate = a["nodes"], a["shapes"], acc["root_of"], acc["gate_next"]
     NONE = 0xFFFFFFFF
     has = np.flatnonzero(roots != NONE)
-    assert len(has) == 6  # dragons.yaml: six dragon.obj instances, each one covered subtree
     an, at = acc["nodes"], acc["tris"]
     covered = np.zeros(len(shapes), dtype=int)
     tops = set()
@@ -197,7 +218,9 @@ def test_aux_bvh_is_well_formed(obj_files):
             f, n = int(nodes["first_shape"][i]), int(nodes["n_shapes"][i])
             in_sub[f:f + n] = True
     assert np.array_equal(covered, in_sub.astype(int)), "every triangle of a covered subtree sits in exactly one leaf"
-    assert len(tops) == 1, "the six instances of dragon.obj share one tree"
+    if one_tree:
+        assert len(tops) == 1, "the six instances of dragon.obj share one tree"
+    return has
 
 
 def test_flatten_matches_committed_hashes(obj_files):

@@ -118,6 +118,21 @@ def test_small_dragons_matches_oracle():
     assert g.stats["refract"] > 0 and g.stats["reflect"] > 0  # the transparent shadow-less bbox cubes are in play
 
 
+def test_oversized_subtrees_covered_piecewise_match_oracle(monkeypatch):
+    """A subtree beyond the size of one auxiliary tree is covered by trees over its child groups, and its own
+    triangles keep the reference's linear tests (rt_accel.h; RT_AUX_MAX_TRIS lowers the 3.1 M limit for the test):
+    the same bytes as with whole-subtree trees, and the oracle's ids."""
+    scene = small_dragons()
+    cam = scene.camera(600, 240)
+    whole = scene.build(host.new_world(0)).render(cam, aux=True)
+    monkeypatch.setenv("RT_AUX_MAX_TRIS", "700")
+    g = scene.build(host.new_world(0)).render(cam, aux=True)
+    monkeypatch.delenv("RT_AUX_MAX_TRIS")
+    assert np.array_equal(g.rgb, whole.rgb) and np.array_equal(g.object_id, whole.object_id)
+    r = scene.build(_oracle().new_world()).render(cam, aux=True)
+    check(g, r, "small dragons, split subtrees")
+
+
 def test_color_at_random_rays(obj_files):
     """rt_color_at vs World::color_at / Intersections::hit of the oracle on arbitrary rays, including
     axis-parallel directions (|d| < 1e-4 slab rule, Q7) and non-unit directions."""
