@@ -65,7 +65,7 @@ def main():
     # it so that every dispatch of the render kernel in a profile is a full frame of the workload)
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--force-gather", action="store_true")  # rehearse the N > 1 exchange step on one GPU (RCCL, world 1)
-    ap.add_argument("--cpu-sample-pixels", type=int, default=900000)  # ~15 s of oracle work on 16 threads
+    ap.add_argument("--cpu-sample-pixels", type=int, default=900000)  # ~15 s of oracle work on 16 threads (the box's CPU share)
     args = ap.parse_args()
 
     # stdout carries the one JSON line and nothing else: libraries that print there (RCCL's version banner) go to stderr
@@ -280,18 +280,71 @@ def main():
                 best = min(best, st.kernel_ms)
             eighths_ms.append(round(best, 3))
 
+    # the other BASELINE.json configurations at 3840x2160, a few frames each, outside the timed region: the driver's
+    # line then carries every config's frame time (BASELINE.md section 4 is filled from it)
+    other = None
+    if world == 1 and rank == 0 and not args.no_extras and args.workload == "dragons":
+        other = {}
+        for name in ("cover", "csg", "checkered_sphere", "soft_shadows"):
+            osc, _ = load_workload(name)
+            ocam = osc.camera(args.width, args.height)
+            ohw = osc.build(host.new_world(local_rank))
+            octx, odsc = ohw.device_scene()
+            orcam = ohw.rt_camera(ocam)
+            obuf = torch.empty((ocam.vsize, ocam.hsize, 3), dtype=torch.float32, device=dev)
+            oo = abi.RtRenderOptions(abi.RT_JITTER_COUNTER, 0.5, 1, args.tile_h, 1, 0, 0)
+            oc = abi.RtRenderOptions(abi.RT_JITTER_COUNTER, 0.5, 1, args.tile_h, 1, 0, abi.RT_RENDER_COUNT_WORK)
+            ost = abi.RtStats()
+
+            def ocheck(rc, what):
+                if rc != abi.RT_OK:
+                    raise RuntimeError(f"{what} failed ({rc}): {lib.rt_last_error(octx).decode()}")
+
+            ocheck(lib.rt_render_device(octx, odsc, C.byref(orcam), C.byref(oc), obuf.data_ptr(), None,
+                                        C.c_void_p(stream.cuda_stream), C.byref(ost)), f"rt_render_device({name}, count)")
+            orays = ost.primary + ost.shadow + ost.reflect + ost.refract
+            for _ in range(3):
+                ocheck(lib.rt_render_device(octx, odsc, C.byref(orcam), C.byref(oo), obuf.data_ptr(), None,
+                                            C.c_void_p(stream.cuda_stream), None), f"rt_render_device({name})")
+            torch.cuda.synchronize(dev)
+            nfr = 10
+            th = time.perf_counter()
+            for _ in range(nfr):
+                ocheck(lib.rt_render_device(octx, odsc, C.byref(orcam), C.byref(oo), obuf.data_ptr(), None,
+                                            C.c_void_p(stream.cuda_stream), None), f"rt_render_device({name})")
+            ocheck(lib.rt_check(octx, C.c_void_p(stream.cuda_stream)), f"rt_check({name})")
+            fms = (time.perf_counter() - th) / nfr * 1e3
+            other[f"{name}.yaml {ocam.hsize}x{ocam.vsize}"] = {
+                "frame_ms": round(fms, 3), "mrays_s": round(orays / fms / 1e3, 1), "rays_per_frame": int(orays),
+                "rays_reference": int(ost.rays_reference), "frames": nfr}
+            del ohw, obuf
+
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle
         from raytracer_amd.builder import JITTER_COUNTER, RenderOptions
         stepn = max(1, int(round((cam.hsize * cam.vsize / args.cpu_sample_pixels) ** 0.5)))
-        threads = min(16, os.cpu_count() or 1)
+        # the threads this process may use: its CPU affinity, and on a shared box the share the harness states in
+        # OMP_NUM_THREADS (os.cpu_count() there is the whole machine, many times this job's share); both counts and the
+        # CPU model go into the line
+        threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        if os.environ.get("OMP_NUM_THREADS", "").isdigit():
+            threads = max(1, min(threads, int(os.environ["OMP_NUM_THREADS"])))
+        cpu_model = "unknown"
+        try:
+            with open("/proc/cpuinfo") as f:
+                for ln in f:
+                    if ln.startswith("model name"):
+                        cpu_model = ln.split(":", 1)[1].strip()
+                        break
+        except OSError:
+            pass
         ow = scene.build(oracle.new_world())
         ro = RenderOptions(jitter_mode=JITTER_COUNTER, seed=1, threads=threads, row_step=stepn, col_step=stepn)
         r = ow.render(cam, ro)
         rays = r.stats["primary"] + r.stats["shadow"] + r.stats["reflect"] + r.stats["refract"]
         cpu_baseline = {"value": round(rays / r.stats["seconds"] / 1e6, 4), "unit": "Mrays/s", "cores": threads,
-                        "kind": "port",
+                        "kind": "port", "host_cpus": os.cpu_count(), "cpu_model": cpu_model,
                         "sample": f"every {stepn}th row and column of the same frame "
                                   f"({r.stats['primary']} primary rays, {r.stats['seconds']:.1f} s); C++ restatement "
                                   f"of the reference (oracle/), not the Rust reference itself"}
@@ -301,6 +354,10 @@ def main():
             "metric": "Mrays/s (primary+shadow+secondary)", "value": round(value, 2), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            # the same frame through rt_render (the boundary: canvas in page-locked HOST memory, PCIe included); `value`
+            # is the frame left in HBM (rt_render_device)
+            "value_at_boundary": round(total_rays / (host_pinned_ms[0] * 1e-3) / 1e6, 2) if host_pinned_ms else None,
+            "value_at_boundary_u8": round(total_rays / (host_pinned_ms[1] * 1e-3) / 1e6, 2) if host_pinned_ms else None,
             "data": "synthetic" if "synthetic" in mesh_label or args.workload != "dragons" else "real",
             "config": {"workload": f"{args.workload}.yaml {cam.hsize}x{cam.vsize} recursion_limit 4 {mesh_label}".strip(),
                        "tile_h": args.tile_h, "parts": world, "rays_per_frame": int(total_rays),
@@ -310,7 +367,8 @@ def main():
                        "frame_ms": round(ms_per_step, 3), "host_frame_ms": host_frame_ms, "host_frame_u8_ms": host_frame_u8_ms,
                        "host_frame_pinned_ms": host_pinned_ms[0] if host_pinned_ms else None,
                        "host_frame_u8_pinned_ms": host_pinned_ms[1] if host_pinned_ms else None,
-                       "eighths_kernel_ms": eighths_ms, "scene_setup_s": round(setup_s, 2)},
+                       "eighths_kernel_ms": eighths_ms, "scene_setup_s": round(setup_s, 2),
+                       "other_workloads": other},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         sys.stdout.flush()

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 1u
+#define RT_ABI_VERSION 2u
 
 enum {
   RT_OK = 0,

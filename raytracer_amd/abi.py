@@ -5,7 +5,7 @@ import ctypes as C
 
 import numpy as np
 
-RT_ABI_VERSION = 1
+RT_ABI_VERSION = 2
 RT_OK, RT_E_ABI, RT_E_DEVICE, RT_E_OOM, RT_E_SCENE, RT_E_OVERFLOW, RT_E_LIMIT = 0, -1, -2, -3, -4, -5, -6
 RT_STATIC_MAX_RAYS = 65536
 RT_SHAPE_KIND_MASK, RT_SHAPE_SHADOW, RT_SHAPE_CLOSED = 0xF, 0x10, 0x20

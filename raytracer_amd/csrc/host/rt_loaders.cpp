@@ -309,7 +309,16 @@ int ppm_decode(const uint8_t* data, size_t len, uint32_t* w, uint32_t* h, std::v
   if (*w == 0 || *h == 0 || maxval == 0) return fail("PPM: empty image or maxval 0");
   if (maxval > 255)
     return fail("PPM: maxval > 255: what the reference's decoder does with 16-bit samples before dividing is not pinned");
+  // (w * h * 3 floats must be addressable: a header that promises more is refused before anything is sized by it)
+  if ((uint64_t)*w * (uint64_t)*h > (uint64_t)SIZE_MAX / 12u) return fail("PPM: image too large");
   const size_t n = (size_t)*w * *h * 3;
+  if (!ascii) {
+    // P6: exactly one whitespace byte separates maxval from the samples; a file that ends at the maxval token, or in
+    // the middle of the samples, is truncated (checked before the buffer is sized or read)
+    if (p >= e || !(*p == ' ' || *p == '\t' || *p == '\r' || *p == '\n' || *p == '\v' || *p == '\f'))
+      return fail("PPM: truncated (no whitespace byte after maxval)");
+    if ((size_t)(e - (p + 1)) < n) return fail("PPM: fewer samples than the header promises");
+  }
   rgb.resize(n);
   const float mv = (float)maxval;
   if (ascii) {
@@ -374,8 +383,7 @@ int ppm_decode(const uint8_t* data, size_t len, uint32_t* w, uint32_t* h, std::v
       if (pc.error == 2) return fail("PPM: sample above maxval");
     }
   } else {
-    p++;  // the single whitespace byte after maxval
-    if ((size_t)(e - p) < n) return fail("PPM: fewer samples than the header promises");
+    p++;  // the single whitespace byte after maxval (present, and n bytes behind it: checked above)
     for (size_t i = 0; i < n; i++) rgb[i] = (float)p[i] / mv;
   }
   return 0;
@@ -476,12 +484,47 @@ int rtl_group_add_obj(RtbWorld* world, int group, const RtbMaterial* material, c
   const int rc = parse_obj(text, len, threads, d);
   if (rc != 0) return rc;
   const bool has_n = !d.normals.empty();
+  // A file with one group hands its tables over as they are.  With several groups each gets tables of the vertices it
+  // uses (in order of first use, indices remapped): rth_group_add_mesh hashes and keeps the tables it is given per mesh,
+  // so whole-file tables would cost O(groups x vertices) time and memory (CAD exports have thousands of `g` sections).
+  const bool compact = d.names.size() > 1;
+  std::vector<int32_t> pos_map, nrm_map;  // file index -> index in the group's table, stamped per group
+  std::vector<uint32_t> pos_stamp, nrm_stamp;
+  if (compact) {
+    pos_map.resize(d.positions.size() / 3);
+    pos_stamp.assign(d.positions.size() / 3, 0xFFFFFFFFu);
+    nrm_map.resize(d.normals.size() / 3);
+    nrm_stamp.assign(d.normals.size() / 3, 0xFFFFFFFFu);
+  }
+  std::vector<float> gpos, gnrm;
+  std::vector<int32_t> gv, gn;
   for (size_t g = 0; g < d.names.size(); g++) {  // one child group per OBJ group (obj.rs:12-38)
     const uint32_t t0 = d.group_first[g], t1 = d.group_first[g + 1];
-    const int child = rth_group_add_mesh(world, group, material, d.positions.data(), (int)(d.positions.size() / 3),
-                                         has_n ? d.normals.data() : nullptr, (int)(d.normals.size() / 3),
-                                         d.vidx.data() + 3 * (size_t)t0, has_n ? d.nidx.data() + 3 * (size_t)t0 : nullptr,
-                                         (int)(t1 - t0));
+    int child;
+    if (!compact) {
+      child = rth_group_add_mesh(world, group, material, d.positions.data(), (int)(d.positions.size() / 3),
+                                 has_n ? d.normals.data() : nullptr, (int)(d.normals.size() / 3),
+                                 d.vidx.data() + 3 * (size_t)t0, has_n ? d.nidx.data() + 3 * (size_t)t0 : nullptr,
+                                 (int)(t1 - t0));
+    } else {
+      gpos.clear(), gnrm.clear(), gv.clear(), gn.clear();
+      auto remap = [&](int32_t idx, std::vector<int32_t>& map, std::vector<uint32_t>& stamp, const std::vector<float>& src,
+                       std::vector<float>& dst) -> int32_t {
+        if (idx < 0) return idx;  // "no normal at this corner" markers pass through
+        if (stamp[(size_t)idx] != (uint32_t)g) {
+          stamp[(size_t)idx] = (uint32_t)g;
+          map[(size_t)idx] = (int32_t)(dst.size() / 3);
+          dst.insert(dst.end(), src.begin() + 3 * (size_t)idx, src.begin() + 3 * (size_t)idx + 3);
+        }
+        return map[(size_t)idx];
+      };
+      for (size_t k = 3 * (size_t)t0; k < 3 * (size_t)t1; k++) {
+        gv.push_back(remap(d.vidx[k], pos_map, pos_stamp, d.positions, gpos));
+        if (has_n) gn.push_back(remap(d.nidx[k], nrm_map, nrm_stamp, d.normals, gnrm));
+      }
+      child = rth_group_add_mesh(world, group, material, gpos.data(), (int)(gpos.size() / 3), has_n ? gnrm.data() : nullptr,
+                                 (int)(gnrm.size() / 3), gv.data(), has_n ? gn.data() : nullptr, (int)(t1 - t0));
+    }
     if (child < 0) return fail(std::string("rth_group_add_mesh: ") + rth_last_error(world), child);
   }
   return (int)d.names.size();

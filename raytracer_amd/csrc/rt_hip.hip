@@ -1395,7 +1395,11 @@ int rt_color_at_static(RtContext* ctx, const RtDeviceScene* ds, const RtRenderOp
   // the array keeps the last call's contents: the counter block is zeroed by color_at_run, every output word the
   // caller reads (entries 0..n) is written by the kernel
   // (may_grow = false: growing the side lists would allocate)
-  return color_at_run(ctx, ds, opts, origins, directions, n, remaining, out_rgb, hit_t, hit_id, hit_uv, stats, b, block, t0, false);
+  const int rc = color_at_run(ctx, ds, opts, origins, directions, n, remaining, out_rgb, hit_t, hit_id, hit_uv, stats, b, block, t0, false);
+  // the array is shared by every context on this GPU: after a failure in the middle of the call (a copy or an event
+  // record) the kernel or copies may still be in flight on it, so the call only returns once the stream is idle
+  if (rc != RT_OK) (void)hipStreamSynchronize(ctx->stream);
+  return rc;
 }
 
 }  // extern "C"

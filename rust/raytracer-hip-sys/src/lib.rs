@@ -9,7 +9,7 @@
 
 use std::os::raw::{c_char, c_int, c_void};
 
-pub const RT_ABI_VERSION: u32 = 1;
+pub const RT_ABI_VERSION: u32 = 2;
 
 pub const RT_OK: c_int = 0;
 pub const RT_E_ABI: c_int = -1;

@@ -197,6 +197,64 @@ def test_ppm_decode_refuses_what_is_not_pinned():
         loaders.ppm_decode(b"P3\n1 1\n10\n1 2 30\n")
 
 
+def test_truncated_p6_files_are_refused_before_anything_is_read():
+    """A P6 file that ends at the maxval token, one byte later, or one byte short of its samples (the
+    first used to step past the end of the caller's buffer); and a header whose sizes overflow."""
+    with pytest.raises(RuntimeError, match="truncated"):
+        loaders.ppm_decode(b"P6 1 1 255")
+    with pytest.raises(RuntimeError, match="truncated"):
+        loaders.ppm_decode(b"P6 1 1 255#")
+    with pytest.raises(RuntimeError, match="fewer samples"):
+        loaders.ppm_decode(b"P6 1 1 255\n")
+    with pytest.raises(RuntimeError, match="fewer samples"):
+        loaders.ppm_decode(b"P6 1 1 255\n\x01\x02")
+    assert np.array_equal(loaders.ppm_decode(b"P6 1 1 255\n\x00\x33\xff")[0, 0],
+                          np.array([0, 0x33, 255], dtype=np.float32) / np.float32(255))
+    for hdr in (b"P6 4294967295 4294967295 255\n", b"P3 4294967295 4294967295 255\n", b"P6 4294967295 3 255\n"):
+        with pytest.raises(RuntimeError, match="too large|fewer samples"):
+            loaders.ppm_decode(hdr + b"\x00" * 16)
+
+
+def test_obj_groups_get_tables_of_their_own_vertices():
+    """A file with many `g` sections: every group is handed only the vertices it uses (rtl_group_add_obj), and the
+    flattened world is the one the whole-file tables give (the Python reader passes those)."""
+    rng = np.random.RandomState(11)
+    n_groups, per = 40, 12
+    lines, nv = [], 0
+    for g in range(n_groups):
+        lines.append(f"g part{g}")
+        for _ in range(per):
+            x, y, z = rng.uniform(-1, 1, 3) + g
+            lines.append(f"v {x:.6f} {y:.6f} {z:.6f}")
+            lines.append(f"vn {rng.uniform(-1, 1):.6f} {rng.uniform(-1, 1):.6f} 1.0")
+        for k in range(per - 2):
+            a, b, c = nv + 1, nv + k + 2, nv + k + 3
+            lines.append(f"f {a}//{a} {b}//{b} {c}//{c}")
+        nv += per
+    # a last group that reaches back into the first groups' vertices, by relative indices too
+    lines += ["g reach", f"f 1//1 {per + 2}//{per + 2} -1//-1"]
+    data = ("\n".join(lines) + "\n").encode()
+    mat = B.Material(color=(0.2, 0.4, 0.6))
+
+    def world(native):
+        w = host.new_world(0)
+        g = w.group([("translate", 0.5, 0, 0)])
+        if native:
+            assert loaders.group_add_obj(w, g, mat, data, threads=3) == n_groups + 1
+        else:
+            for og in loaders.parse_obj_bytes(data):
+                w.group_add_mesh(g, mat, og["positions"], og["normals"], og["vidx"], og["nidx"])
+        w.add_group(g)
+        w.add_point_light((0, 10, -10), (1, 1, 1))
+        return abi.scene_arrays(w.flatten())
+
+    a, b = world(True), world(False)
+    assert a.keys() == b.keys()
+    for k in a:
+        assert np.asarray(a[k]).tobytes() == np.asarray(b[k]).tobytes(), k
+    assert len(a["tri_geom"]) == n_groups * (per - 2) + 1
+
+
 def test_uv_image_from_ppm_is_the_texture_the_python_path_uploads(tmp_path):
     rng = np.random.RandomState(4)
     px = rng.randint(0, 256, size=(16, 24, 3)).astype(np.uint8)
