@@ -332,6 +332,28 @@ void rt_host_free(RtContext*, void* p);
 int rt_render_device(RtContext*, const RtDeviceScene*, const RtCamera*, const RtRenderOptions*, float* d_out_rgb,
                      RtAux* d_aux, void* stream, RtStats* stats);
 
+/* Camera::render (src/camera.rs:66-84) over SEVERAL GPUs of one host, called from one thread like the reference's:
+ * ctxs[g] / scenes[g] are n contexts (1 <= n <= 16, each listed once) with the same world uploaded to each
+ * (rt_scene_create per context).  Context g renders the rows r with (r / tile_h) % n == g (opts->tile_h, 8 if 0;
+ * opts->n_parts / part are ignored) -- pixels are independent (src/camera.rs:73-77), area-light jitter is keyed by the
+ * absolute pixel, so the canvas is the same bytes for every n -- all GPUs launched before any is waited for.
+ *   rt_render_multi         writes the whole canvas, vsize*hsize*3 f32, to HOST memory: every GPU copies its stripes
+ *                           straight to their places in out_rgb over its own PCIe link (no GPU-to-GPU traffic).  With
+ *                           out_rgb from rt_host_alloc the copies are asynchronous DMAs and one thread drives all GPUs;
+ *                           into pageable memory one thread per GPU is started for the call.
+ *   rt_render_multi_device  leaves the whole canvas in d_out_rgb on ctxs[0]'s GPU: the parts are gathered there over
+ *                           xGMI with RCCL (grouped ncclSend / ncclRecv; librccl.so is opened on first use, RT_RCCL_LIB
+ *                           names another file) and put in order by a de-interleave kernel.  n == 1 renders in place.
+ * stats (may be NULL): n entries, one per context.  Both are synchronous.  With n == 1 they equal rt_render /
+ * rt_render_device byte for byte.  Contexts that share a GPU are accepted (tests on a one-GPU box); the device variant
+ * then copies inside that GPU instead of going through RCCL, which takes a device once per communicator. */
+#define RT_MULTI_MAX 16u
+int rt_device_count(void); /* HIP devices visible to this process (0 if none), for hosts that do not link HIP themselves */
+int rt_render_multi(RtContext* const* ctxs, const RtDeviceScene* const* scenes, uint32_t n, const RtCamera*,
+                    const RtRenderOptions*, float* out_rgb, RtStats* stats);
+int rt_render_multi_device(RtContext* const* ctxs, const RtDeviceScene* const* scenes, uint32_t n, const RtCamera*,
+                           const RtRenderOptions*, float* d_out_rgb, RtStats* stats);
+
 /* Synchronises `stream` (NULL: every stream of the context's GPU) and returns RT_E_OVERFLOW if any launch on this
  * context since the last synchronising call overflowed a per-ray list, RT_OK otherwise; clears the condition and gives
  * the context (larger) side lists, so that the same frames rendered again come out right.

@@ -101,7 +101,8 @@ AUX_TRI = np.dtype([("p1", "<f4", 3), ("shape", "<u4"), ("e1", "<f4", 3), ("owne
 assert AUX_NODE.itemsize == 128 and AUX_TRI.itemsize == 48
 
 EXPORTS = ["rt_host_alloc", "rt_host_free", "rt_accel_build", "rt_accel_free", "rt_abi_version", "rt_context_create", "rt_context_destroy", "rt_last_error", "rt_scene_create",
-           "rt_scene_destroy", "rt_part_rows", "rt_render", "rt_render_u8", "rt_canvas_to_u8_device", "rt_render_device", "rt_check", "rt_color_at", "rt_color_at_static"]
+           "rt_scene_destroy", "rt_part_rows", "rt_render", "rt_render_u8", "rt_canvas_to_u8_device", "rt_render_device", "rt_check", "rt_color_at", "rt_color_at_static", "rt_device_count", "rt_render_multi",
+           "rt_render_multi_device"]
 
 
 def declare(lib: C.CDLL) -> None:
@@ -129,6 +130,12 @@ def declare(lib: C.CDLL) -> None:
     lib.rt_render_device.argtypes = [P, P, C.POINTER(RtCamera), C.POINTER(RtRenderOptions), P, C.POINTER(RtAux), P,
                                      C.POINTER(RtStats)]
     lib.rt_check.restype, lib.rt_check.argtypes = C.c_int, [P, P]
+    lib.rt_device_count.restype, lib.rt_device_count.argtypes = C.c_int, []
+    lib.rt_render_multi.restype = C.c_int
+    lib.rt_render_multi.argtypes = [C.POINTER(P), C.POINTER(P), C.c_uint32, C.POINTER(RtCamera), C.POINTER(RtRenderOptions), P,
+                                    C.POINTER(RtStats)]
+    lib.rt_render_multi_device.restype = C.c_int
+    lib.rt_render_multi_device.argtypes = lib.rt_render_multi.argtypes
     lib.rt_color_at.restype = C.c_int
     lib.rt_color_at.argtypes = [P, P, C.POINTER(RtRenderOptions), P, P, C.c_uint32, C.c_uint32, P, P, P, P,
                                 C.POINTER(RtStats)]

@@ -532,6 +532,13 @@ struct RtbWorld {
   RtContext* ctx = nullptr;
   RtDeviceScene* dscene = nullptr;
   int device = 0;
+  // further GPUs that render a share of every frame (rth_set_devices; rt_render_multi): context and resident scene each
+  struct MoreGpu {
+    int device = 0;
+    RtContext* ctx = nullptr;
+    RtDeviceScene* dscene = nullptr;
+  };
+  std::vector<MoreGpu> more;
 
   ~RtbWorld() { drop_device(); }
   void drop_device() {
@@ -539,6 +546,12 @@ struct RtbWorld {
     dscene = nullptr;
     if (ctx) rt_context_destroy(ctx);
     ctx = nullptr;
+    for (MoreGpu& m : more) {
+      if (m.dscene) rt_scene_destroy(m.ctx, m.dscene);
+      if (m.ctx) rt_context_destroy(m.ctx);
+      m.dscene = nullptr;
+      m.ctx = nullptr;
+    }
   }
   void touch() {
     dirty = true;
@@ -546,6 +559,11 @@ struct RtbWorld {
       rt_scene_destroy(ctx, dscene);
       dscene = nullptr;
     }
+    for (MoreGpu& m : more)
+      if (m.dscene) {
+        rt_scene_destroy(m.ctx, m.dscene);
+        m.dscene = nullptr;
+      }
   }
 
   // ---- shapes ---------------------------------------------------------------------------
@@ -1693,6 +1711,21 @@ int rth_set_device(RtbWorld* w, int device) {
   w->device = device;
   return 0;
 }
+// Camera::render on several GPUs: devices[0] is the world's device (rt_color_at, aux outputs), the others take a
+// share of the rows of every frame rendered without aux outputs (rt_render_multi).  An ordinal may be listed more than
+// once (several contexts on one GPU: what a test on a one-GPU box does).
+int rth_set_devices(RtbWorld* w, const int* devices, int n) {
+  if (!devices || n < 1 || n > (int)RT_MULTI_MAX) return fail(w, "rth_set_devices: 1 .. RT_MULTI_MAX devices");
+  w->drop_device();
+  w->device = devices[0];
+  w->more.clear();
+  for (int k = 1; k < n; k++) {
+    RtbWorld::MoreGpu m;
+    m.device = devices[k];
+    w->more.push_back(m);
+  }
+  return 0;
+}
 const RtScene* rth_flatten(RtbWorld* w) {
   if (!w->flatten()) return nullptr;
   return &w->flat->view;
@@ -1711,6 +1744,16 @@ int rth_device_scene(RtbWorld* w, RtContext** ctx, RtDeviceScene** scene) {
   if (!w->dscene) {
     int rc = rt_scene_create(w->ctx, &w->flat->view, &w->dscene);
     if (rc != RT_OK) return fail(w, std::string("rt_scene_create: ") + rt_last_error(w->ctx), rc);
+  }
+  for (RtbWorld::MoreGpu& m : w->more) {
+    if (!m.ctx) {
+      int rc = rt_context_create(m.device, &m.ctx);
+      if (rc != RT_OK) return fail(w, "rt_context_create failed for GPU " + std::to_string(m.device), rc);
+    }
+    if (!m.dscene) {
+      int rc = rt_scene_create(m.ctx, &w->flat->view, &m.dscene);
+      if (rc != RT_OK) return fail(w, std::string("rt_scene_create: ") + rt_last_error(m.ctx), rc);
+    }
   }
   if (ctx) *ctx = w->ctx;
   if (scene) *scene = w->dscene;
@@ -1733,7 +1776,26 @@ int rth_render(RtbWorld* w, const RtbCamera* cam, const RtbRenderOptions* opts, 
     ra.hit_t = aux->hit_t;
   }
   RtStats rs{};
-  int r = rt_render(w->ctx, w->dscene, &rc, &ro, out_rgb, aux ? &ra : nullptr, &rs);
+  int r;
+  if (!w->more.empty() && !aux) {  // every GPU renders its stripes of rows and copies them into out_rgb
+    std::vector<RtContext*> ctxs{w->ctx};
+    std::vector<const RtDeviceScene*> scenes{w->dscene};
+    for (RtbWorld::MoreGpu& m : w->more) {
+      ctxs.push_back(m.ctx);
+      scenes.push_back(m.dscene);
+    }
+    std::vector<RtStats> per(ctxs.size());
+    r = rt_render_multi(ctxs.data(), scenes.data(), (uint32_t)ctxs.size(), &rc, &ro, out_rgb, per.data());
+    for (const RtStats& p : per) {
+      rs.primary += p.primary;
+      rs.shadow += p.shadow;
+      rs.reflect += p.reflect;
+      rs.refract += p.refract;
+      rs.overflow += p.overflow;
+    }
+  } else {
+    r = rt_render(w->ctx, w->dscene, &rc, &ro, out_rgb, aux ? &ra : nullptr, &rs);
+  }
   if (stats) {
     stats->primary = rs.primary;
     stats->shadow = rs.shadow;

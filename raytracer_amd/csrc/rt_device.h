@@ -549,6 +549,28 @@ __device__ __forceinline__ int reported_shape(const Scene& sc, int s) {
   return (w0.x & RT_SHAPE_KIND_MASK) >= RT_TRIANGLE ? (int)w1.z : s;
 }
 
+// The local_intersect of a shape's kind (shapes.rs:208-245) on a ray in the shape's space.
+template <class Sink>
+__device__ __forceinline__ void shape_test_local(const Scene& sc, uint32_t si, uint32_t kf, uint32_t prim, float mn, float mx,
+                                                 const Ray& local, Sink& sink) {
+  float ts[4];
+  int n = 0;
+  switch (kf & RT_SHAPE_KIND_MASK) {
+    case RT_SPHERE: n = isect_sphere(local, ts); break;
+    case RT_PLANE: n = isect_plane(local, ts); break;
+    case RT_CUBE: n = isect_cube(local, ts); break;
+    case RT_CYLINDER: n = isect_cylinder(local, mn, mx, (kf & RT_SHAPE_CLOSED) != 0, ts); break;
+    case RT_CONE: n = isect_cone(local, mn, mx, (kf & RT_SHAPE_CLOSED) != 0, ts); break;
+    default: {
+      V3 p1, e1, e2;
+      load_tri(sc, prim, p1, e1, e2);
+      float t, u, v;
+      if (isect_triangle(local, p1, e1, e2, t, u, v)) sink.add(t, si, u, v);
+      return;
+    }
+  }
+  for (int i = 0; i < n; i++) sink.add(ts[i], si, 0.f, 0.f);
+}
 // Shape::intersect (shapes.rs:204-246): inverse-transform the ray, dispatch on kind.
 // CULL: the kernel variant for scenes that have cull records (decided per scene: the test costs registers and ~25
 // operations per shape, which only pays where a ray meets many shapes in a row)
@@ -572,23 +594,20 @@ __device__ __forceinline__ void shape_intersect(const Scene& sc, uint32_t si, co
   }
   float mn = __uint_as_float(w1.z), mx = __uint_as_float(w1.w);
   Ray local = xform ? xf_ray(sc, xform, ray) : ray;
-  float ts[4];
-  int n = 0;
-  switch (kf & RT_SHAPE_KIND_MASK) {
-    case RT_SPHERE: n = isect_sphere(local, ts); break;
-    case RT_PLANE: n = isect_plane(local, ts); break;
-    case RT_CUBE: n = isect_cube(local, ts); break;
-    case RT_CYLINDER: n = isect_cylinder(local, mn, mx, (kf & RT_SHAPE_CLOSED) != 0, ts); break;
-    case RT_CONE: n = isect_cone(local, mn, mx, (kf & RT_SHAPE_CLOSED) != 0, ts); break;
-    default: {
-      V3 p1, e1, e2;
-      load_tri(sc, prim, p1, e1, e2);
-      float t, u, v;
-      if (isect_triangle(local, p1, e1, e2, t, u, v)) sink.add(t, si, u, v);
-      return;
-    }
-  }
-  for (int i = 0; i < n; i++) sink.add(ts[i], si, 0.f, 0.f);
+  shape_test_local(sc, si, kf, prim, mn, mx, local, sink);
+}
+// Shape::intersect for a ray whose ORIGIN is already in the shape's space (`local_o` = the shape's inverse transform
+// applied to the ray's origin, Ray::transform's first half, rays.rs:19-24): the many rays that leave one point -- the
+// shadow rays of an area light's samples (lights.rs:123-134) -- transform it once.  Same expressions on the same values
+// as shape_intersect => same bits.
+template <class Sink>
+__device__ __forceinline__ void shape_intersect_from(const Scene& sc, uint32_t si, const V3 local_o, const V3 dir, Sink& sink) {
+  const u4n RT_CONST_AS* raw = cst(reinterpret_cast<const u4n*>(sc.shapes + si));
+  u4n w0 = raw[0], w1 = raw[1];
+  const uint32_t kf = w0.x, xform = w0.y, prim = w1.y;
+  if (!sink.takes(kf)) return;
+  const Ray local{local_o, xform ? xf_vector(cst(sc.xforms)[xform].m, dir) : dir};
+  shape_test_local(sc, si, kf, prim, __uint_as_float(w1.z), __uint_as_float(w1.w), local, sink);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -2093,6 +2112,76 @@ __device__ __forceinline__ Hit direct_closest(const Scene& sc, const Ray& ray, C
   simple_intersect<COUNT>(sc, ray, sink, cn);
   return Hit{sink.t, sink.u(), sink.v(), sink.shape};
 }
+// The shadow rays of one hit all leave over_point (world.rs:101-105): a world of a few loose shapes and no csg keeps that
+// point in every shape's space (RT_HOIST_SHAPES of them: 12 registers), so a ray costs each shape the transform of its
+// direction only, and tests the shadow-casting shapes first: World::is_shadowed asks whether the CLOSEST hit casts a
+// shadow, i.e. whether some hit X on a shadow-casting shape lies before the light and no hit on a shadow-less shape lies
+// before X in (t, rank) order -- without an X the shadow-less shapes (soft_shadows.yaml: the cube around the light,
+// the dearest test of the four) need not be looked at.
+#define RT_HOIST_SHAPES 4u
+// (only in the HOIST instantiation of the direct kernel, which the host launches for worlds of at most RT_HOIST_SHAPES
+// loose shapes and nothing else: rt_hip.hip launch_part.  The points live in LDS, one column per lane, so that the
+// loop over the shapes stays a loop: unrolled for registers it was eight inlined copies of Shape::intersect and 250
+// spilled registers.)
+struct ShadowOrigin {
+  uint32_t off;
+  __device__ __forceinline__ float* base() const {
+    __shared__ float pts[3u * RT_HOIST_SHAPES * RT_BLOCK];
+    return pts;
+  }
+  __device__ __forceinline__ V3 get(uint32_t k) const {
+    const float* b = base();
+    return v3(b[(3u * k) * RT_BLOCK + off], b[(3u * k + 1u) * RT_BLOCK + off], b[(3u * k + 2u) * RT_BLOCK + off]);
+  }
+  __device__ __forceinline__ void put(uint32_t k, V3 p) const {
+    float* b = base();
+    b[(3u * k) * RT_BLOCK + off] = p.x;
+    b[(3u * k + 1u) * RT_BLOCK + off] = p.y;
+    b[(3u * k + 2u) * RT_BLOCK + off] = p.z;
+  }
+};
+__device__ __forceinline__ ShadowOrigin shadow_origin(const Scene& sc, V3 p) {
+  ShadowOrigin so{threadIdx.x};
+  for (uint32_t k = 0; k < sc.n_loose && k < RT_HOIST_SHAPES; k++) {
+    const uint32_t xform = cst(sc.shapes)[sc.n_shapes - sc.n_loose + k].xform;
+    so.put(k, xform ? xf_point(cst(sc.xforms)[xform].m, p) : p);
+  }
+  return so;
+}
+template <bool COUNT>
+__device__ __forceinline__ bool hoisted_is_shadowed(const Scene& sc, const ShadowOrigin& so, V3 light_position, V3 p,
+                                                    Counters& cn, uint32_t mult) {
+  V3 v = light_position - p;
+  float distance = magnitude(v);
+  V3 direction = v / distance;
+  cn.shadow++;
+  if (COUNT) cn.ref_rays += mult;
+  if (COUNT) cn.shape_tests += sc.n_loose;
+  const uint32_t first = sc.n_shapes - sc.n_loose;
+  // pass 0, X: the closest hit on a shadow-casting shape in front of the light (a CLOSEST search that skips the
+  // shadow-less shapes); pass 1: a hit on a shadow-less shape before X in (t, rank) order?  (a CLOSEST_NOSHADOW
+  // search that starts from X)
+  Sink sink;
+  sink.init_closest();
+  sink.set_cap(distance);
+  int x_shape = -1;
+  for (uint32_t pass = 0; pass < 2u; pass++) {
+    for (uint32_t k = 0; k < sc.n_loose; k++) {
+      const bool casts = (cst(sc.shapes)[first + k].kind_flags & RT_SHAPE_SHADOW) != 0u;
+      if (casts == (pass == 0u)) shape_intersect_from(sc, first + k, so.get(k), direction, sink);
+    }
+    if (pass == 1u) break;
+    x_shape = sink.shape;
+    if (!wave_any(x_shape >= 0) || !(sc.props & RT_SCENE_HAS_NOSHADOW)) break;  // nobody in the wave has an X, or nothing is shadow-less
+    const float tx = sink.t;
+    sink.init(SINK_CLOSEST_NOSHADOW);
+    sink.t = tx;
+    sink.shape = x_shape;
+    sink.lim = x_shape >= 0 ? tx : -__builtin_inff();  // (a lane without an X has nothing to look for)
+    sink.bound = x_shape >= 0 ? sink.bound : -__builtin_inff();
+  }
+  return x_shape >= 0 && sink.shape == x_shape;
+}
 // World::is_shadowed (world.rs:101-111), see Sink::init_any_shadow for the two equivalent searches
 template <bool COUNT>
 __device__ __forceinline__ bool direct_is_shadowed(const Scene& sc, V3 light_position, V3 p, Counters& cn, uint32_t mult) {
@@ -2113,7 +2202,7 @@ __device__ __forceinline__ bool direct_is_shadowed(const Scene& sc, V3 light_pos
   return sink.found();
 }
 
-template <bool COUNT>
+template <bool COUNT, bool HOIST = false>
 __device__ __forceinline__ V3 color_at_direct(const Scene& sc, const RenderParams& rp, Ray primary, uint32_t remaining0,
                               uint32_t pixel, Counters& cn, Hit* primary_hit) {
   PendingRay stack[RT_MAX_RAY_STACK];
@@ -2181,7 +2270,12 @@ __device__ __forceinline__ V3 color_at_direct(const Scene& sc, const RenderParam
       V3 surface;
       if (L.kind == RT_LIGHT_POINT) {
         V3 lpos = v3(L.position[0], L.position[1], L.position[2]);
-        float intensity = direct_is_shadowed<COUNT>(sc, lpos, over_point, cn, mult) ? 0.f : 1.f;  // lights.rs:50-56
+        bool shadowed;
+        if constexpr (HOIST)
+          shadowed = hoisted_is_shadowed<COUNT>(sc, shadow_origin(sc, over_point), lpos, over_point, cn, mult);
+        else
+          shadowed = direct_is_shadowed<COUNT>(sc, lpos, over_point, cn, mult);
+        float intensity = shadowed ? 0.f : 1.f;  // lights.rs:50-56
         V3 diffuse = v3(0.f, 0.f, 0.f), specular = v3(0.f, 0.f, 0.f);
         phong_sample(lpos, over_point, eyev, normalv, effective, lcol, m_diffuse, m_specular, m_shininess, diffuse,
                      specular);
@@ -2189,10 +2283,17 @@ __device__ __forceinline__ V3 color_at_direct(const Scene& sc, const RenderParam
       } else {
         // AreaLight::intensity_at (lights.rs:123-134)
         float total = 0.f;
+        ShadowOrigin so;
+        if (HOIST) so = shadow_origin(sc, over_point);
         for (uint32_t u = 0; u < L.usteps; u++)
           for (uint32_t v = 0; v < L.vsteps; v++) {
             V3 lpos = point_on_light(L, li, u, v, 0u, rp, pixel, pr.path);
-            if (!direct_is_shadowed<COUNT>(sc, lpos, over_point, cn, mult)) total += 1.f;
+            bool shadowed;
+            if constexpr (HOIST)
+              shadowed = hoisted_is_shadowed<COUNT>(sc, so, lpos, over_point, cn, mult);
+            else
+              shadowed = direct_is_shadowed<COUNT>(sc, lpos, over_point, cn, mult);
+            if (!shadowed) total += 1.f;
           }
         float nb = (float)(L.usteps * L.vsteps);
         float intensity = total / nb;

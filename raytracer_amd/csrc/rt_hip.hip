@@ -4,13 +4,18 @@
 //   -fhip-fp32-correctly-rounded-divide-sqrt -fPIC -shared
 // No FMA contraction and correctly rounded / and sqrt are REQUIRED for parity.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // declarations only: librccl.so is opened when rt_render_multi_device first gathers (rccl_api)
 
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "rt_accel.h"
@@ -219,8 +224,15 @@ void k_render_jobs(Scene sc, RtCamera cam, RenderParams rp, PartInfo part, Pixel
 #ifndef RT_DIRECT_WAVES_PER_EU
 #define RT_DIRECT_WAVES_PER_EU 4
 #endif
-#define RT_DIRECT_ATTR __attribute__((amdgpu_waves_per_eu(RT_DIRECT_WAVES_PER_EU, RT_DIRECT_WAVES_PER_EU)))
-template <bool COUNT>
+#ifndef RT_HOIST_WAVES_PER_EU
+// the HOIST instantiation (soft_shadows.yaml 4K): 3 / 4 / 5 / 6 / 8 waves per SIMD = 9.66 / 8.51 / 7.92 / 7.75 / 7.79 ms
+// with 0 / 38 / 77 / 166 / 204 spilled registers
+#define RT_HOIST_WAVES_PER_EU 5
+#endif
+#define RT_DIRECT_ATTR \
+  __attribute__((amdgpu_waves_per_eu(HOIST ? RT_HOIST_WAVES_PER_EU : RT_DIRECT_WAVES_PER_EU, HOIST ? RT_HOIST_WAVES_PER_EU : RT_DIRECT_WAVES_PER_EU)))
+// HOIST: worlds of at most RT_HOIST_SHAPES loose shapes and nothing else (rt_device.h hoisted_is_shadowed)
+template <bool COUNT, bool HOIST>
 __global__ __launch_bounds__(RT_BLOCK) RT_DIRECT_ATTR
 void k_render_direct(Scene sc, RtCamera cam, RenderParams rp, PartInfo part, PixelOut o, unsigned long long* counters) {
   const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -238,7 +250,7 @@ void k_render_direct(Scene sc, RtCamera cam, RenderParams rp, PartInfo part, Pix
     cn.primary = 1;
     if (COUNT) cn.ref_rays = 1;
     Hit ph;
-    V3 col = color_at_direct<COUNT>(sc, rp, ray_for_pixel(cam, px, py), sc.recursion_limit, py * cam.hsize + px, cn, &ph);
+    V3 col = color_at_direct<COUNT, HOIST>(sc, rp, ray_for_pixel(cam, px, py), sc.recursion_limit, py * cam.hsize + px, cn, &ph);
     ph.shape = reported_shape(sc, ph.shape);
     write_hit(o, (size_t)ly * cam.hsize + px, ph);
     write_colour<COUNT>(sc, o, (size_t)ly * cam.hsize + px, col,
@@ -375,6 +387,27 @@ __global__ __launch_bounds__(256) void k_canvas_to_u8(const float* __restrict__ 
       o[wd] = bytes[4 * wd] | (bytes[4 * wd + 1] << 8) | (bytes[4 * wd + 2] << 16) | (bytes[4 * wd + 3] << 24);
   } else {
     for (uint32_t k = 0; k < 3u * cnt; k++) out[3u * p0 + k] = (uint8_t)bytes[k];
+  }
+}
+
+// The canvas of a frame that n GPUs rendered as interleaved parts, from the parts laid one after the other
+// in `parts` (part g's rows_of(g) compacted rows from row first[g] on): row r of the canvas is row
+// (r / (tile_h n)) tile_h + r % tile_h of part (r / tile_h) % n.  16 bytes per thread where the rows allow it.
+struct PartLayout {
+  uint32_t n, tile_h, vsize, row_floats;
+  uint32_t first[16];  // RT_MULTI_MAX parts
+};
+__global__ __launch_bounds__(256) void k_deinterleave(const float* __restrict__ parts, float* __restrict__ canvas, PartLayout L) {
+  const uint32_t r = blockIdx.y;
+  const uint32_t g = (r / L.tile_h) % L.n;
+  const uint32_t lr = (r / (L.tile_h * L.n)) * L.tile_h + r % L.tile_h;
+  const float* src = parts + (size_t)(L.first[g] + lr) * L.row_floats;
+  float* dst = canvas + (size_t)r * L.row_floats;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if ((L.row_floats & 3u) == 0u && ((((uintptr_t)parts) | ((uintptr_t)canvas)) & 15u) == 0u) {
+    if (i * 4u < L.row_floats) reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[i];
+  } else {
+    for (uint32_t k = i * 4u; k < i * 4u + 4u && k < L.row_floats; k++) dst[k] = src[k];
   }
 }
 
@@ -1021,8 +1054,10 @@ static int launch_part(RtContext* ctx, const Scene& sc, const RtCamera* cam, con
   if (direct) {
     const uint32_t tile = RT_BLOCK == 256 ? 16u : 8u;
     dim3 grid((cam->hsize + tile - 1) / tile, (part.rows + tile - 1) / tile);
-    hipLaunchKernelGGL(count ? k_render_direct<true> : k_render_direct<false>, grid, dim3(RT_BLOCK), 0, stream, sc, *cam,
-                       rp, part, po, d_counters);
+    const bool hoist = sc.n_csg_roots == 0 && sc.n_loose <= RT_HOIST_SHAPES && !std::getenv("RT_NO_HOIST");
+    auto kern = count ? (hoist ? k_render_direct<true, true> : k_render_direct<true, false>)
+                      : (hoist ? k_render_direct<false, true> : k_render_direct<false, false>);
+    hipLaunchKernelGGL(kern, grid, dim3(RT_BLOCK), 0, stream, sc, *cam, rp, part, po, d_counters);
   } else {
     // persistent waves: enough blocks to fill the device at four waves per SIMD, never more than the work
     const uint64_t items = (uint64_t)((cam->hsize + 7u) / 8u) * ((part.rows + 7u) / 8u) * 64u;
@@ -1267,6 +1302,370 @@ int rt_render_u8(RtContext* ctx, const RtDeviceScene* ds, const RtCamera* cam, c
                  uint8_t* out_u8, RtAux* aux, RtStats* stats) {
   if (!out_u8) return RT_E_ABI;
   return render_host(ctx, ds, cam, opts, nullptr, out_u8, dither, aux, stats);
+}
+
+// =========================================================================================
+// Camera::render over several GPUs of one host: context g renders the rows r with
+// (r / tile_h) % n == g of the frame, every context on a stream of its own, all launched before any is waited for.
+//   rt_render_multi         canvas in HOST memory (what Camera::render returns): every GPU copies its stripes straight
+//                           to where they belong in the caller's canvas (a strided copy over its own PCIe link); no
+//                           GPU-to-GPU traffic at all.
+//   rt_render_multi_device  canvas in the first context's HBM: the parts are gathered there over xGMI (RCCL send /
+//                           recv in one group) and put in order by k_deinterleave.
+// =========================================================================================
+namespace {
+struct RcclApi {
+  void* lib = nullptr;
+  decltype(&ncclCommInitAll) CommInitAll = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclSend) Send = nullptr;
+  decltype(&ncclRecv) Recv = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  std::string error;
+};
+// librccl.so is opened on first use: a host that renders on one GPU never loads it.  RT_RCCL_LIB names another file.
+RcclApi* rccl_api() {
+  static RcclApi api;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    const char* name = std::getenv("RT_RCCL_LIB");
+    for (const char* cand : {name, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      if (!cand) continue;
+      api.lib = dlopen(cand, RTLD_NOW | RTLD_LOCAL);
+      if (api.lib) break;
+    }
+    if (!api.lib) {
+      api.error = std::string("librccl.so could not be opened: ") + (dlerror() ? dlerror() : "not found");
+      return;
+    }
+    bool ok = true;
+    auto sym = [&](const char* n) {
+      void* p = dlsym(api.lib, n);
+      if (!p) {
+        ok = false;
+        api.error = std::string("librccl.so lacks ") + n;
+      }
+      return p;
+    };
+    api.CommInitAll = reinterpret_cast<decltype(api.CommInitAll)>(sym("ncclCommInitAll"));
+    api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
+    api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(sym("ncclGroupStart"));
+    api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(sym("ncclGroupEnd"));
+    api.Send = reinterpret_cast<decltype(api.Send)>(sym("ncclSend"));
+    api.Recv = reinterpret_cast<decltype(api.Recv)>(sym("ncclRecv"));
+    api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
+    if (!ok) {
+      dlclose(api.lib);
+      api.lib = nullptr;
+    }
+  });
+  return &api;
+}
+// One communicator per distinct list of devices, made when that list first gathers and kept until the process ends.
+struct CommSet {
+  std::vector<int> devices;
+  std::vector<ncclComm_t> comms;
+};
+std::mutex g_comm_mutex;
+std::vector<CommSet*> g_comm_sets;
+int multi_comms(RtContext* c0, const std::vector<int>& devices, CommSet** out) {
+  std::lock_guard<std::mutex> lock(g_comm_mutex);
+  for (CommSet* cs : g_comm_sets)
+    if (cs->devices == devices) {
+      *out = cs;
+      return RT_OK;
+    }
+  RcclApi* api = rccl_api();
+  if (!api->lib) return fail(c0, RT_E_DEVICE, "rt_render_multi_device: " + api->error);
+  CommSet* cs = new CommSet();
+  cs->devices = devices;
+  cs->comms.resize(devices.size());
+  ncclResult_t r = api->CommInitAll(cs->comms.data(), (int)devices.size(), devices.data());
+  if (r != ncclSuccess) {
+    delete cs;
+    return fail(c0, RT_E_DEVICE, std::string("ncclCommInitAll: ") + api->GetErrorString(r));
+  }
+  g_comm_sets.push_back(cs);
+  *out = cs;
+  return RT_OK;
+}
+
+// What one GPU does for a multi-GPU frame: its part into its own frame buffer (or `d_direct`), asynchronously.
+struct MultiPart {
+  PartInfo part;
+  unsigned slot = 0;
+  unsigned long long* block = nullptr;
+  float* d_rgb = nullptr;
+  bool launched = false;
+};
+int multi_frame_buffer(RtContext* ctx, size_t floats) {
+  const size_t need = (floats ? floats : 1) * sizeof(float);
+  if (ctx->frame_bytes[0] >= need) return RT_OK;
+  if (ctx->d_frame[0]) (void)hipFree(ctx->d_frame[0]);
+  ctx->d_frame[0] = nullptr;
+  ctx->frame_bytes[0] = 0;
+  hipError_t e = hipMalloc(&ctx->d_frame[0], need);
+  if (e != hipSuccess) return fail(ctx, e == hipErrorOutOfMemory ? RT_E_OOM : RT_E_DEVICE, std::string("frame buffer: ") + hipGetErrorString(e));
+  ctx->frame_bytes[0] = need;
+  return RT_OK;
+}
+int multi_launch(RtContext* ctx, const RtDeviceScene* ds, const RtCamera* cam, const RtRenderOptions* opts, MultiPart& mp,
+                 bool want_events) {
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  Scene sc = ds->sc;
+  sc.flags = opts ? opts->flags : 0;
+  sc.sticky = ctx->d_sticky;
+  attach_side(ctx, sc);
+  RenderParams rp = make_params(opts);
+  int rc = ring_acquire(ctx, ctx->stream, &mp.slot, &mp.block);
+  if (rc != RT_OK) return rc;
+  if (want_events) HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  rc = launch_part(ctx, sc, cam, rp, mp.part, mp.d_rgb, nullptr, ctx->stream, mp.block);
+  if (rc != RT_OK) return rc;
+  if (want_events) HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  mp.launched = true;
+  return ring_release(ctx, ctx->stream, mp.slot);
+}
+// The rows of part g, compacted on the device, to their places in the caller's canvas: stripe k of the part is rows
+// [(k n + g) tile_h, + tile_h) of the frame, so the whole stripes are ONE strided copy ("rows" of tile_h image rows,
+// n tile_h image rows apart) and a last, shorter stripe is a second one.
+int multi_copy_out(RtContext* ctx, const RtCamera* cam, const MultiPart& mp, float* out_rgb) {
+  const size_t row_bytes = (size_t)cam->hsize * 3 * sizeof(float);
+  const PartInfo& p = mp.part;
+  const uint32_t whole = p.rows / p.tile_h, rest = p.rows % p.tile_h;
+  char* dst = reinterpret_cast<char*>(out_rgb) + (size_t)p.part * p.tile_h * row_bytes;
+  if (whole)
+    HIP_TRY(ctx, hipMemcpy2DAsync(dst, (size_t)p.n_parts * p.tile_h * row_bytes, mp.d_rgb, (size_t)p.tile_h * row_bytes,
+                                  (size_t)p.tile_h * row_bytes, whole, hipMemcpyDeviceToHost, ctx->stream));
+  if (rest)
+    HIP_TRY(ctx, hipMemcpyAsync(dst + (size_t)whole * p.n_parts * p.tile_h * row_bytes,
+                                reinterpret_cast<const char*>(mp.d_rgb) + (size_t)whole * p.tile_h * row_bytes, rest * row_bytes,
+                                hipMemcpyDeviceToHost, ctx->stream));
+  return RT_OK;
+}
+// After the part's stream is idle: counters, and the cure for a list overflow (side lists, the part again).  `redo`
+// re-renders and re-delivers the part synchronously.
+int multi_settle(RtContext* ctx, MultiPart& mp, RtStats* stats, double total_ms, const std::function<int()>& redo) {
+  unsigned long long earlier = 0;
+  while (true) {
+    RtStats local{};
+    int rc = read_stats(ctx, ctx->stream, &local, total_ms, 1, mp.block);
+    if (rc != RT_OK) return rc;
+    if (stats) *stats = local;
+    bool retry = false;
+    rc = settle_overflow(ctx, ctx->stream, local.overflow, true, &retry, &earlier);
+    if (!retry) return rc;
+    rc = redo();
+    if (rc != RT_OK) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  }
+}
+int multi_check_args(RtContext* const* ctxs, const RtDeviceScene* const* scenes, uint32_t n, const RtCamera* cam,
+                     const void* out) {
+  if (!ctxs || !scenes || !cam || !out || n == 0 || n > RT_MULTI_MAX) return RT_E_ABI;
+  for (uint32_t g = 0; g < n; g++) {
+    if (!ctxs[g] || !scenes[g]) return RT_E_ABI;
+    if (scenes[g]->owner != ctxs[g]) return fail(ctxs[g], RT_E_ABI, "scene belongs to another context");
+    for (uint32_t k = 0; k < g; k++)
+      if (ctxs[k] == ctxs[g]) return fail(ctxs[0], RT_E_ABI, "rt_render_multi: a context is listed twice");
+  }
+  if (cam->hsize == 0 || cam->vsize == 0) return fail(ctxs[0], RT_E_ABI, "empty camera");
+  return RT_OK;
+}
+RtRenderOptions multi_options(const RtRenderOptions* opts, uint32_t n, uint32_t g) {
+  RtRenderOptions o{};
+  if (opts) o = *opts;
+  if (!opts) {
+    o.jitter_mode = RT_JITTER_CONST;
+    o.jitter_value = 0.5f;
+  }
+  if (o.tile_h == 0) o.tile_h = 8;  // stripes as tall as the kernel's 8x8 tiles
+  o.n_parts = n;
+  o.part = g;
+  return o;
+}
+}  // namespace
+
+int rt_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+int rt_render_multi(RtContext* const* ctxs, const RtDeviceScene* const* scenes, uint32_t n, const RtCamera* cam,
+                    const RtRenderOptions* opts, float* out_rgb, RtStats* stats) {
+  int rc = multi_check_args(ctxs, scenes, n, cam, out_rgb);
+  if (rc != RT_OK) return rc;
+  auto t0 = std::chrono::steady_clock::now();
+  std::vector<MultiPart> mp(n);
+  std::vector<RtRenderOptions> po(n);
+  // a copy into pageable memory keeps the calling thread busy for its whole length: one thread per GPU then
+  bool locked = false;
+  {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, out_rgb) == hipSuccess)
+      locked = at.type == hipMemoryTypeHost;
+    else
+      (void)hipGetLastError();
+  }
+  auto one = [&](uint32_t g) -> int {
+    RtContext* ctx = ctxs[g];
+    po[g] = multi_options(opts, n, g);
+    mp[g].part = make_part(cam, &po[g]);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int r = multi_frame_buffer(ctx, (size_t)mp[g].part.rows * cam->hsize * 3);
+    if (r != RT_OK) return r;
+    mp[g].d_rgb = static_cast<float*>(ctx->d_frame[0]);
+    r = multi_launch(ctx, scenes[g], cam, &po[g], mp[g], true);
+    if (r != RT_OK) return r;
+    return multi_copy_out(ctx, cam, mp[g], out_rgb);
+  };
+  auto finish = [&](uint32_t g) -> int {
+    RtContext* ctx = ctxs[g];
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const double total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return multi_settle(ctx, mp[g], stats ? &stats[g] : nullptr, total, [&]() -> int {
+      int r = multi_launch(ctx, scenes[g], cam, &po[g], mp[g], true);
+      return r != RT_OK ? r : multi_copy_out(ctx, cam, mp[g], out_rgb);
+    });
+  };
+  std::vector<int> rcs(n, RT_OK);
+  if (locked || n == 1) {
+    for (uint32_t g = 0; g < n; g++) rcs[g] = one(g);  // every GPU is launched (and its copy queued) before any is waited for
+    for (uint32_t g = 0; g < n; g++)
+      if (rcs[g] == RT_OK) rcs[g] = finish(g);
+  } else {
+    std::vector<std::thread> pool;
+    for (uint32_t g = 0; g < n; g++)
+      pool.emplace_back([&, g] {
+        rcs[g] = one(g);
+        if (rcs[g] == RT_OK) rcs[g] = finish(g);
+      });
+    for (auto& t : pool) t.join();
+  }
+  for (uint32_t g = 0; g < n; g++)
+    if (rcs[g] != RT_OK) {
+      (void)hipSetDevice(ctxs[g]->device);
+      (void)hipStreamSynchronize(ctxs[g]->stream);
+      if (g != 0) ctxs[0]->error = "GPU " + std::to_string(ctxs[g]->device) + ": " + ctxs[g]->error;
+      return rcs[g];
+    }
+  return RT_OK;
+}
+
+int rt_render_multi_device(RtContext* const* ctxs, const RtDeviceScene* const* scenes, uint32_t n, const RtCamera* cam,
+                           const RtRenderOptions* opts, float* d_out_rgb, RtStats* stats) {
+  int rc = multi_check_args(ctxs, scenes, n, cam, d_out_rgb);
+  if (rc != RT_OK) return rc;
+  auto t0 = std::chrono::steady_clock::now();
+  RtContext* c0 = ctxs[0];
+  std::vector<MultiPart> mp(n);
+  std::vector<RtRenderOptions> po(n);
+  PartLayout L{};
+  L.n = n;
+  L.vsize = cam->vsize;
+  L.row_floats = cam->hsize * 3u;
+  uint32_t rows_all = 0;
+  for (uint32_t g = 0; g < n; g++) {
+    po[g] = multi_options(opts, n, g);
+    mp[g].part = make_part(cam, &po[g]);
+    L.first[g] = rows_all;
+    rows_all += mp[g].part.rows;
+  }
+  L.tile_h = po[0].tile_h;
+  // RT_MULTI_FORCE_GATHER=1: one GPU goes through the exchange step as well (the rehearsal the tests use)
+  const bool gather = n > 1 || std::getenv("RT_MULTI_FORCE_GATHER") != nullptr;
+  // the first context's frame buffer holds all parts one after the other: its own part is rendered in place
+  HIP_TRY(c0, hipSetDevice(c0->device));
+  if (gather) {
+    rc = multi_frame_buffer(c0, (size_t)rows_all * L.row_floats);
+    if (rc != RT_OK) return rc;
+  }
+  for (uint32_t g = 0; g < n; g++) {
+    RtContext* ctx = ctxs[g];
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (g == 0) {
+      mp[g].d_rgb = gather ? static_cast<float*>(c0->d_frame[0]) : d_out_rgb;
+    } else {
+      rc = multi_frame_buffer(ctx, (size_t)mp[g].part.rows * L.row_floats);
+      if (rc != RT_OK) return rc;
+      mp[g].d_rgb = static_cast<float*>(ctx->d_frame[0]);
+    }
+    rc = multi_launch(ctx, scenes[g], cam, &po[g], mp[g], true);
+    if (rc != RT_OK) return rc;
+  }
+  auto exchange = [&]() -> int {
+    if (!gather) return RT_OK;
+    bool distinct = true;
+    for (uint32_t g = 0; g < n; g++)
+      for (uint32_t k = 0; k < g; k++) distinct = distinct && ctxs[g]->device != ctxs[k]->device;
+    float* staging = static_cast<float*>(c0->d_frame[0]);
+    if (distinct) {
+      std::vector<int> devices(n);
+      for (uint32_t g = 0; g < n; g++) devices[g] = ctxs[g]->device;
+      CommSet* cs = nullptr;
+      int r = multi_comms(c0, devices, &cs);
+      if (r != RT_OK) return r;
+      RcclApi* api = rccl_api();
+      ncclResult_t nr = api->GroupStart();
+      // (one rank: RCCL copies the part onto itself, the rehearsal on one GPU)
+      for (uint32_t g = (n == 1 ? 0u : 1u); g < n && nr == ncclSuccess; g++) {
+        const size_t count = (size_t)mp[g].part.rows * L.row_floats;
+        if (!count) continue;
+        nr = api->Recv(staging + (size_t)L.first[g] * L.row_floats, count, ncclFloat, (int)g, cs->comms[0], c0->stream);
+        if (nr == ncclSuccess) nr = api->Send(mp[g].d_rgb, count, ncclFloat, 0, cs->comms[g], ctxs[g]->stream);
+      }
+      const ncclResult_t ne = api->GroupEnd();
+      if (nr == ncclSuccess) nr = ne;
+      if (nr != ncclSuccess) return fail(c0, RT_E_DEVICE, std::string("RCCL gather: ") + api->GetErrorString(nr));
+    } else {
+      // several contexts on one GPU (tests on a single-GPU box): RCCL takes a device once per communicator, and the
+      // "exchange" is a copy inside that GPU's memory, ordered behind each part's render
+      for (uint32_t g = 1; g < n; g++) {
+        if (ctxs[g]->device != c0->device) return fail(c0, RT_E_ABI, "rt_render_multi_device: contexts share some GPUs but not all");
+        const size_t bytes = (size_t)mp[g].part.rows * L.row_floats * sizeof(float);
+        HIP_TRY(c0, hipEventRecord(ctxs[g]->ev_band[0], ctxs[g]->stream));
+        HIP_TRY(c0, hipStreamWaitEvent(c0->stream, ctxs[g]->ev_band[0], 0));
+        if (bytes)
+          HIP_TRY(c0, hipMemcpyAsync(staging + (size_t)L.first[g] * L.row_floats, mp[g].d_rgb, bytes, hipMemcpyDeviceToDevice, c0->stream));
+      }
+    }
+    HIP_TRY(c0, hipSetDevice(c0->device));
+    hipLaunchKernelGGL(k_deinterleave, dim3((L.row_floats / 4u + 256u) / 256u, cam->vsize), dim3(256), 0, c0->stream, staging,
+                       d_out_rgb, L);
+    HIP_TRY(c0, hipGetLastError());
+    return RT_OK;
+  };
+  rc = exchange();
+  if (rc != RT_OK) return rc;
+  // every part's stream, then the first context's (the gather and the de-interleave are on it)
+  bool again = false;
+  for (uint32_t g = n; g-- > 0;) {
+    RtContext* ctx = ctxs[g];
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const double total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    rc = multi_settle(ctx, mp[g], stats ? &stats[g] : nullptr, total, [&]() -> int {
+      again = true;
+      return multi_launch(ctx, scenes[g], cam, &po[g], mp[g], true);
+    });
+    if (rc != RT_OK) return rc;
+  }
+  if (again) {  // a part was rendered again (its intersection lists had overflowed): gather once more
+    rc = exchange();
+    if (rc != RT_OK) return rc;
+    for (uint32_t g = 0; g < n; g++) {
+      HIP_TRY(ctxs[g], hipSetDevice(ctxs[g]->device));
+      HIP_TRY(ctxs[g], hipStreamSynchronize(ctxs[g]->stream));
+    }
+  }
+  return RT_OK;
 }
 
 namespace {

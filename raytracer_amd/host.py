@@ -47,6 +47,8 @@ def host_lib() -> C.CDLL:
         _host.rth_flatten.argtypes = [C.c_void_p]
         _host.rth_set_device.restype = C.c_int
         _host.rth_set_device.argtypes = [C.c_void_p, C.c_int]
+        _host.rth_set_devices.restype = C.c_int
+        _host.rth_set_devices.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int]
         _host.rth_make_camera.restype = C.c_int
         _host.rth_make_camera.argtypes = [C.c_void_p, C.POINTER(CameraC), C.POINTER(abi.RtCamera)]
         _host.rth_device_scene.restype = C.c_int
@@ -57,9 +59,15 @@ def host_lib() -> C.CDLL:
 class HostWorld(WorldBuilder):
     """World on the product path, plus access to the flattened scene and the C-ABI handles."""
 
-    def __init__(self, device: int = 0):
+    def __init__(self, device=0):
+        """device: a HIP ordinal, or a list of them: frames rendered without aux outputs are then shared between those
+        GPUs (rt_render_multi); an ordinal listed twice means two contexts on that GPU."""
         super().__init__(host_lib(), "rth_")
-        self.lib.rth_set_device(self.w, device)
+        if isinstance(device, (list, tuple)):
+            arr = (C.c_int * len(device))(*device)
+            self._check(self.lib.rth_set_devices(self.w, arr, len(device)), "set_devices")
+        else:
+            self.lib.rth_set_device(self.w, device)
 
     def flatten(self) -> "abi.RtScene":
         p = self.lib.rth_flatten(self.w)
@@ -84,5 +92,5 @@ class HostWorld(WorldBuilder):
         return ctx, sc
 
 
-def new_world(device: int = 0) -> HostWorld:
+def new_world(device=0) -> HostWorld:
     return HostWorld(device)

@@ -330,6 +330,7 @@ pub const RT_DITHER_BAYER16: u32 = 4;
 pub const RT_DITHER_BAYER_COLOR: u32 = 5;
 
 pub const RT_STATIC_MAX_RAYS: u32 = 65536;
+pub const RT_MULTI_MAX: u32 = 16;
 
 extern "C" {
     pub fn rt_abi_version() -> u32;
@@ -379,6 +380,25 @@ extern "C" {
         d_out_rgb: *mut f32,
         d_aux: *mut RtAux,
         stream: *mut c_void,
+        stats: *mut RtStats,
+    ) -> c_int;
+    pub fn rt_device_count() -> c_int;
+    pub fn rt_render_multi(
+        ctxs: *const *mut RtContext,
+        scenes: *const *const RtDeviceScene,
+        n: u32,
+        cam: *const RtCamera,
+        opts: *const RtRenderOptions,
+        out_rgb: *mut f32,
+        stats: *mut RtStats,
+    ) -> c_int;
+    pub fn rt_render_multi_device(
+        ctxs: *const *mut RtContext,
+        scenes: *const *const RtDeviceScene,
+        n: u32,
+        cam: *const RtCamera,
+        opts: *const RtRenderOptions,
+        d_out_rgb: *mut f32,
         stats: *mut RtStats,
     ) -> c_int;
     pub fn rt_check(ctx: *mut RtContext, stream: *mut c_void) -> c_int;

@@ -758,18 +758,83 @@ fn rt_camera(cam: &Camera) -> Result<RtCamera, String> {
     })
 }
 
-/// One context per process and GPU, created on first use (RT_HIP_DEVICE selects the ordinal, default 0).
-struct Gpu(*mut RtContext);
-unsafe impl Send for Gpu {}
+/// One context per GPU of the host, created on first use.  RT_HIP_DEVICES lists the ordinals to use ("0,2,3"),
+/// RT_HIP_DEVICE names a single one; without either every device rt_device_count() reports is used, and a frame is
+/// rendered by all of them at once (rt_render_multi: GPU g renders the rows r with (r / 8) % n == g).
+struct Gpus(Vec<*mut RtContext>);
+unsafe impl Send for Gpus {}
 
-impl Drop for Gpu {
+impl Drop for Gpus {
     fn drop(&mut self) {
-        unsafe { rt_context_destroy(self.0) }
+        for &ctx in &self.0 {
+            unsafe { rt_context_destroy(ctx) }
+        }
     }
 }
 
 lazy_static::lazy_static! {
-    static ref GPU: parking_lot::Mutex<Option<Gpu>> = parking_lot::Mutex::new(None);
+    static ref GPU: parking_lot::Mutex<Option<Gpus>> = parking_lot::Mutex::new(None);
+}
+
+fn device_list() -> Result<Vec<i32>, String> {
+    if let Ok(list) = std::env::var("RT_HIP_DEVICES") {
+        let devices: Vec<i32> = list.split(',').filter_map(|s| s.trim().parse().ok()).collect();
+        if devices.is_empty() {
+            return Err("RT_HIP_DEVICES names no device".into());
+        }
+        return Ok(devices);
+    }
+    if let Some(device) = std::env::var("RT_HIP_DEVICE").ok().and_then(|s| s.parse().ok()) {
+        return Ok(vec![device]);
+    }
+    let n = unsafe { rt_device_count() };
+    if n <= 0 {
+        return Err("no GPU visible (rt_device_count)".into());
+    }
+    Ok((0..n.min(RT_MULTI_MAX as i32)).collect())
+}
+
+/// The contexts of this process, creating them on the first call.
+fn contexts(guard: &mut Option<Gpus>) -> Result<Vec<*mut RtContext>, String> {
+    if guard.is_none() {
+        let mut gpus = Gpus(Vec::new());
+        for device in device_list()? {
+            let mut ctx = ptr::null_mut();
+            check(ptr::null_mut(), unsafe { rt_context_create(device, &mut ctx) }, "rt_context_create")?;
+            gpus.0.push(ctx);
+        }
+        *guard = Some(gpus);
+    }
+    Ok(guard.as_ref().unwrap().0.clone())
+}
+
+/// The flattened world in every context's HBM; `f` runs with the scene handles, which are destroyed afterwards.
+fn with_scenes<T>(
+    ctxs: &[*mut RtContext],
+    scene: &RtScene,
+    f: impl FnOnce(&[*const RtDeviceScene]) -> Result<T, String>,
+) -> Result<T, String> {
+    let mut scenes: Vec<*mut RtDeviceScene> = Vec::with_capacity(ctxs.len());
+    let mut result = Ok(());
+    for &ctx in ctxs {
+        let mut d = ptr::null_mut();
+        result = check(ctx, unsafe { rt_scene_create(ctx, scene, &mut d) }, "rt_scene_create");
+        if result.is_err() {
+            break;
+        }
+        scenes.push(d);
+    }
+    let out = match result {
+        Ok(()) => {
+            let views: Vec<*const RtDeviceScene> = scenes.iter().map(|&d| d as *const RtDeviceScene).collect();
+            f(&views)
+        }
+        Err(e) => Err(e),
+    };
+    for (k, &d) in scenes.iter().enumerate() {
+        unsafe { rt_scene_destroy(ctxs[k], d) };
+    }
+    out
 }
 
 fn check(ctx: *mut RtContext, rc: i32, what: &str) -> Result<(), String> {
@@ -805,25 +870,20 @@ pub fn render(cam: &Camera, world: &World) -> Result<Canvas, String> {
     };
     let mut canvas = Canvas::new(cam.hsize, cam.vsize);
     let mut guard = GPU.lock();
-    if guard.is_none() {
-        let device = std::env::var("RT_HIP_DEVICE").ok().and_then(|s| s.parse().ok()).unwrap_or(0);
-        let mut ctx = ptr::null_mut();
-        check(ptr::null_mut(), unsafe { rt_context_create(device, &mut ctx) }, "rt_context_create")?;
-        *guard = Some(Gpu(ctx));
-    }
-    let ctx = guard.as_ref().unwrap().0;
-    let mut dscene = ptr::null_mut();
-    check(ctx, unsafe { rt_scene_create(ctx, &scene, &mut dscene) }, "rt_scene_create")?;
-    // Rgb32FImage is row-major f32 RGB (canvas.rs:10-31): exactly what rt_render writes, unclamped
+    let ctxs = contexts(&mut guard)?;
+    // Rgb32FImage is row-major f32 RGB (canvas.rs:10-31): exactly what rt_render_multi writes, unclamped; with one
+    // GPU it is rt_render byte for byte, with several every GPU copies its stripes of rows into this buffer itself
     let out: &mut [f32] = canvas.buffer_mut();
     debug_assert_eq!(out.len(), cam.hsize as usize * cam.vsize as usize * 3);
-    let r = check(
-        ctx,
-        unsafe { rt_render(ctx, dscene, &rc, &opts, out.as_mut_ptr(), ptr::null_mut(), ptr::null_mut()) },
-        "rt_render",
-    );
-    unsafe { rt_scene_destroy(ctx, dscene) };
-    r?;
+    with_scenes(&ctxs, &scene, |scenes| {
+        check(
+            ctxs[0],
+            unsafe {
+                rt_render_multi(ctxs.as_ptr(), scenes.as_ptr(), ctxs.len() as u32, &rc, &opts, out.as_mut_ptr(), ptr::null_mut())
+            },
+            "rt_render_multi",
+        )
+    })?;
     Ok(canvas)
 }
 
@@ -844,21 +904,15 @@ pub fn render_u8(cam: &Camera, world: &World, dither: u32) -> Result<Vec<u8>, St
     };
     let mut out = vec![0u8; cam.hsize as usize * cam.vsize as usize * 3];
     let mut guard = GPU.lock();
-    if guard.is_none() {
-        let device = std::env::var("RT_HIP_DEVICE").ok().and_then(|s| s.parse().ok()).unwrap_or(0);
-        let mut ctx = ptr::null_mut();
-        check(ptr::null_mut(), unsafe { rt_context_create(device, &mut ctx) }, "rt_context_create")?;
-        *guard = Some(Gpu(ctx));
-    }
-    let ctx = guard.as_ref().unwrap().0;
-    let mut dscene = ptr::null_mut();
-    check(ctx, unsafe { rt_scene_create(ctx, &scene, &mut dscene) }, "rt_scene_create")?;
-    let r = check(
-        ctx,
-        unsafe { rt_render_u8(ctx, dscene, &rc, &opts, dither, out.as_mut_ptr(), ptr::null_mut(), ptr::null_mut()) },
-        "rt_render_u8",
-    );
-    unsafe { rt_scene_destroy(ctx, dscene) };
-    r?;
+    // (the 8-bit frame is a quarter of the bytes: one GPU's link carries it; rt_render_u8 has no multi-GPU form)
+    let ctxs = contexts(&mut guard)?;
+    let ctx = ctxs[0];
+    with_scenes(&ctxs[..1], &scene, |scenes| {
+        check(
+            ctx,
+            unsafe { rt_render_u8(ctx, scenes[0], &rc, &opts, dither, out.as_mut_ptr(), ptr::null_mut(), ptr::null_mut()) },
+            "rt_render_u8",
+        )
+    })?;
     Ok(out)
 }

@@ -423,6 +423,33 @@ def test_soft_shadows_parts_through_direct_kernel(mode):
     assert np.array_equal(canvas.view(np.uint32), sfull.view(np.uint32)) and np.array_equal(idc, sids)
 
 
+def test_soft_shadows_at_4k_in_parts_and_through_both_direct_kernels(monkeypatch):
+    """BASELINE config 4 at its full size: soft_shadows.yaml at 3840x2160, 100 shadow samples a hit, "tiled over 8
+    GPUs".  The eight interleaved parts reassemble to the bytes of the whole frame, and the whole frame is the same
+    bytes through the direct kernel's two instantiations: shadow rays that keep their origin in every shape's space and
+    test the shadow-casting shapes first (rt_device.h hoisted_is_shadowed), and the plain World::is_shadowed loop
+    (RT_NO_HOIST in the environment at launch time)."""
+    from raytracer_amd import tiles
+    scene = Scene.from_file(scene_path("soft_shadows"))
+    size = (3840, 2160)
+    raw = Raw(scene, size)
+    full, ids, st = raw.render()
+    assert st.overflow == 0 and st.primary == size[0] * size[1] and st.shadow > 50 * st.primary
+    canvas, idc, rays = np.full_like(full, np.nan), np.full_like(ids, -9), 0
+    for p in range(8):
+        rgb, oid, s = raw.render(tile_h=8, n_parts=8, part=p)
+        rows = tiles.part_rows(size[1], 8, 8, p)
+        canvas[rows], idc[rows] = rgb, oid
+        rays += s.primary + s.shadow + s.reflect + s.refract
+    assert np.array_equal(canvas.view(np.uint32), full.view(np.uint32)) and np.array_equal(idc, ids)
+    assert rays == st.primary + st.shadow + st.reflect + st.refract
+    del canvas, idc
+    monkeypatch.setenv("RT_NO_HOIST", "1")
+    plain, pids, ps = raw.render()
+    assert np.array_equal(plain.view(np.uint32), full.view(np.uint32)) and np.array_equal(pids, ids)
+    assert (ps.primary, ps.shadow, ps.reflect, ps.refract) == (st.primary, st.shadow, st.reflect, st.refract)
+
+
 @pytest.mark.parametrize("seed", [1, 3, 6])
 def test_fuzz_parts(seed, root):
     """tools/gpu_fuzz.py run_parts: a random world (odd seeds: group-less with an area light, the direct kernel) as one

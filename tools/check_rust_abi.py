@@ -171,7 +171,7 @@ def check_gpu_rs(rconsts, rstructs, rfuncs, ropaque, problems):
     text = re.sub(r"//[^\n]*", " ", open(GPU_RS).read())
     declared = set(rconsts) | set(rstructs) | set(rfuncs) | set(ropaque)
     for name in sorted(set(re.findall(r"\b(RT_[A-Z0-9_]+|Rt[A-Z]\w+|rt_[a-z_0-9]+)\b", text))):
-        if name not in declared and name not in ("rt_camera", "RT_HIP_DEVICE"):  # a local fn / an environment variable
+        if name not in declared and name not in ("rt_camera", "RT_HIP_DEVICE", "RT_HIP_DEVICES"):  # a local fn / environment variables
             problems.append(f"gpu.rs uses {name}, which lib.rs does not declare")
     # struct literals `RtFoo { field: ..., .. }`: every named field exists
     for m in re.finditer(r"\b(Rt[A-Z]\w+)\s*\{", text):
