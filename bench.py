@@ -51,6 +51,61 @@ def load_workload(name: str):
     return scene, label
 
 
+def main_multi_abi(args, json_fd) -> int:
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    rc = 0
+    if rank == 0:
+        devices = [int(x) for x in os.environ["RT_BENCH_DEVICES"].split(",")] if os.environ.get("RT_BENCH_DEVICES") else list(range(args.gpus))
+        if len(devices) != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but RT_BENCH_DEVICES names {len(devices)} devices")
+        lib = host.hip_lib()
+        scene, mesh_label = load_workload(args.workload)
+        cam = scene.camera(args.width, args.height)
+        t0 = time.time()
+        worlds = [scene.build(host.new_world(d)) for d in devices]
+        pairs = [w.device_scene() for w in worlds]
+        setup_s = time.time() - t0
+        n = len(devices)
+        ctxs = (C.c_void_p * n)(*[p[0].value for p in pairs])
+        scenes = (C.c_void_p * n)(*[p[1].value for p in pairs])
+        rcam = worlds[0].rt_camera(cam)
+        dev0 = torch.device("cuda", devices[0])
+        canvas = torch.zeros((cam.vsize, cam.hsize, 3), dtype=torch.float32, device=dev0)
+        torch.cuda.synchronize(dev0)
+        opts = abi.RtRenderOptions(abi.RT_JITTER_COUNTER, 0.5, 1, args.tile_h, 1, 0, 0)
+        stats = (abi.RtStats * n)()
+
+        def frame():
+            r = lib.rt_render_multi_device(ctxs, scenes, n, C.byref(rcam), C.byref(opts), canvas.data_ptr(), stats)
+            if r != abi.RT_OK:
+                raise RuntimeError(f"rt_render_multi_device failed ({r}): {lib.rt_last_error(ctxs[0]).decode()}")
+
+        for _ in range(args.warmup):
+            frame()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            frame()  # (synchronous: the canvas is complete in GPU 0's HBM when it returns)
+        elapsed = time.perf_counter() - t0
+        rays = sum(s.primary + s.shadow + s.reflect + s.refract for s in stats)
+        ms = elapsed / args.steps * 1e3
+        out = {"metric": "Mrays/s (primary+shadow+secondary)", "value": round(rays / ms / 1e3, 2), "unit": "Mrays/s",
+               "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
+               "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic" if "synthetic" in mesh_label or args.workload != "dragons" else "real",
+               "config": {"workload": f"{args.workload}.yaml {cam.hsize}x{cam.vsize} recursion_limit 4 {mesh_label}".strip(),
+                          "tile_h": args.tile_h, "parts": n, "devices": devices, "rays_per_frame": int(rays),
+                          "entry_point": "rt_render_multi_device (one process, RCCL gather into the first GPU's HBM)",
+                          "part_kernel_ms": [round(s.kernel_ms, 3) for s in stats], "scene_setup_s": round(setup_s, 2)},
+               "roofline": None, "cpu_baseline": None}
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -65,6 +120,10 @@ def main():
     # it so that every dispatch of the render kernel in a profile is a full frame of the workload)
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--force-gather", action="store_true")  # rehearse the N > 1 exchange step on one GPU (RCCL, world 1)
+    # N GPUs driven by ONE process through the C ABI (rt_render_multi_device: RCCL gather into GPU 0's HBM), as a host
+    # in the reference's language would do it; under torchrun rank 0 drives them and the other ranks only wait.
+    # RT_BENCH_DEVICES=0,0 rehearses N = 2 on a box with one GPU (two contexts on it).
+    ap.add_argument("--multi-abi", action="store_true")
     ap.add_argument("--cpu-sample-pixels", type=int, default=900000)  # ~15 s of oracle work on 16 threads (the box's CPU share)
     args = ap.parse_args()
 
@@ -73,6 +132,8 @@ def main():
     json_fd = os.dup(1)
     os.dup2(2, 1)
 
+    if args.multi_abi:
+        raise SystemExit(main_multi_abi(args, json_fd))
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # `python bench.py --gpus N` by itself: start one rank per GPU (fresh child processes, nothing here has
         # touched the GPU yet) and relay rank 0's JSON line; under torchrun the ranks already exist

@@ -11,12 +11,27 @@
 
 #include "../../include/rt_abi.h"
 
+// Fixed capacities of the device code where the reference's structures are unbounded.  Two sets: the kernels every
+// sample scene runs through, and the BIG set of the one slow-path instantiation (the SIDE kernels, which also keep the
+// n1/n2 lists in device memory): a world that passes a limit of the first set renders through those instead of being
+// refused (rt_hip.hip validate_scene / RtDeviceScene::needs_big); only past the BIG set is it RT_E_SCENE.
 #define RT_MAX_XF_DEPTH 6    // nested non-identity group transforms along one path
 #define RT_MAX_RAY_STACK 8   // pending secondary rays per pixel (recursion_limit + 1 needed)
 #ifndef RT_CSG_CAP
 #define RT_CSG_CAP 32        // per-ray intersection entries while evaluating one csg tree
 #endif
 #define RT_CSG_DEPTH 8       // csg tree depth
+#define RT_BIG_XF_DEPTH 32
+#define RT_BIG_RAY_STACK 17  // recursion_limit up to 16
+#define RT_BIG_CSG_CAP 256
+#define RT_BIG_CSG_DEPTH 32
+template <bool BIG>
+struct Lim {
+  static constexpr int kXfDepth = BIG ? RT_BIG_XF_DEPTH : RT_MAX_XF_DEPTH;
+  static constexpr int kRayStack = BIG ? RT_BIG_RAY_STACK : RT_MAX_RAY_STACK;
+  static constexpr int kCsgCap = BIG ? RT_BIG_CSG_CAP : RT_CSG_CAP;
+  static constexpr int kCsgDepth = BIG ? RT_BIG_CSG_DEPTH : RT_CSG_DEPTH;
+};
 #ifndef RT_XS_CAP
 #define RT_XS_CAP 96         // per-ray entries for the n1/n2 container walk
 #endif
@@ -418,6 +433,7 @@ enum { SINK_CLOSEST = 0, SINK_COLLECT = 1, SINK_CLOSEST_NOSHADOW = 2, SINK_ANY_S
 // rather than one list that continues in device memory: that version's extra branch in Sink::add, never taken, cost the
 // collect-heavy cover scene 19 % of its frame.
 struct XsList {
+  static constexpr bool kBig = false;
   float t[RT_XS_CAP];
   uint32_t s[RT_XS_CAP];
   __device__ __forceinline__ void attach(const Scene&) {}
@@ -434,6 +450,7 @@ __device__ __forceinline__ char* side_list(const Scene& sc, int which) {
   return sc.side + (lane * SIDE_LISTS + (size_t)which) * sc.side_cap * 4u;
 }
 struct XsSideList {
+  static constexpr bool kBig = true;  // the kernels that keep the lists here are also the ones with the BIG capacities (Lim)
   // (pointers into the GLOBAL address space, declared as such: a store through a generic pointer may alias the
   // per-lane arrays and the LDS state as far as the compiler knows)
   RT_GLOBAL_AS float* t;
@@ -462,6 +479,7 @@ struct XsSideList {
 //               any-shadow: distance to the light, -inf once an occluder is found | collect: keep t <= bound
 template <class List>
 struct SinkT {
+  static constexpr bool kBig = List::kBig;
   float t;
   int shape;
   float a, b;    // closest: (u, v) of the best hit
@@ -615,19 +633,20 @@ __device__ __forceinline__ void shape_intersect_from(const Scene& sc, uint32_t s
 // per-ray entry list; entries are kept sorted by (t total order, insertion rank), which is
 // what the reference's nested stable sorts produce (DESIGN.md "CSG").
 // ---------------------------------------------------------------------------------------
-struct CsgList {
+template <bool BIG>
+struct CsgListT {
   // RT_CSG_CAP entries are enough for every tree rt_scene_create accepts: it adds up the most intersections each leaf
   // can have (validate_scene) and rejects a tree that could pass the capacity, so this list cannot overflow at run time
   // (`overflow` stays as the check of that claim).  A spill path into the side lists was tried twice: as a second,
   // inlined evaluation it cost the render kernel 28 more spilled registers and 5 % of the dragons frame; with the
   // arrays behind pointers the direct kernel spilled thousands.
-  float t[RT_CSG_CAP];
-  uint32_t s[RT_CSG_CAP];
+  float t[Lim<BIG>::kCsgCap];
+  uint32_t s[Lim<BIG>::kCsgCap];
   int n;
   int overflow;
   __device__ __forceinline__ bool takes(uint32_t) const { return true; }
   __device__ __forceinline__ void add(float tt, uint32_t ss, float, float) {
-    if (n < RT_CSG_CAP) {
+    if (n < Lim<BIG>::kCsgCap) {
       t[n] = tt;
       s[n] = ss;
       n++;
@@ -674,8 +693,9 @@ __device__ __forceinline__ bool csg_allowed(uint32_t op, bool l_hit, bool in_l, 
   return (l_hit && !in_r) || (!l_hit && in_l);
 }
 // Evaluates one top-level csg; on return L.t/L.s[0..L.n) is Csg::local_intersect(ray).
-__device__ inline void csg_eval(const Scene& sc, RtCsgRoot root, const Ray& ray, CsgList& L) {
-  int seg[RT_CSG_DEPTH];
+template <bool BIG>
+__device__ inline void csg_eval(const Scene& sc, RtCsgRoot root, const Ray& ray, CsgListT<BIG>& L) {
+  int seg[Lim<BIG>::kCsgDepth];
   int sp = 0;
   L.n = 0;
   for (uint32_t k = root.first; k < root.first + root.count; k++) {
@@ -1131,12 +1151,13 @@ __device__ inline void aux_coop(const Scene& sc, const uint32_t root_node, const
 // node's space is rebuilt from the world ray through that node's chain of transformed ancestors
 // (same matrices in the same order => same bits).
 // ---------------------------------------------------------------------------------------
+template <bool BIG = false>
 __device__ inline Ray ray_in_space_of(const Scene& sc, int xf_node, const Ray& world) {
   // xf_node: innermost transformed group whose space is wanted (-1 = world)
-  int chain[RT_MAX_XF_DEPTH];
+  int chain[Lim<BIG>::kXfDepth];
   int n = 0;
   int q = xf_node;
-  while (q >= 0 && n < RT_MAX_XF_DEPTH) {
+  while (q >= 0 && n < Lim<BIG>::kXfDepth) {
     chain[n++] = q;
     int par = cst(sc.nodes)[q].parent;
     q = par >= 0 ? cst(sc.nodes)[par].next_xf : -1;
@@ -1161,7 +1182,7 @@ __device__ RT_WI_INLINE void world_intersect(const Scene& sc, const Ray& ray, Si
   // `active` false: this lane has no ray to trace but still takes part in the wave-wide votes of the walk
   // csgs first (world.rs:45-49)
   if (sc.n_csg_roots && active) {
-    CsgList L;
+    CsgListT<Sink::kBig> L;
     L.overflow = 0;
     for (uint32_t c = 0; c < sc.n_csg_roots; c++) {
       csg_eval(sc, sc.csg_roots[c], ray, L);
@@ -1197,7 +1218,7 @@ __device__ RT_WI_INLINE void world_intersect(const Scene& sc, const Ray& ray, Si
         if (i >= leave_at) {
           int par = (int)w2.w;
           int q = par >= 0 ? cst(sc.nodes)[par].next_xf : -1;
-          cur = q >= 0 ? ray_in_space_of(sc, q, ray) : ray;
+          cur = q >= 0 ? ray_in_space_of<Sink::kBig>(sc, q, ray) : ray;
           leave_at = q >= 0 ? cst(sc.nodes)[q].skip : 0xFFFFFFFFu;
         }
         RT_UTIL(2);
@@ -1291,14 +1312,15 @@ __device__ RT_WI_INLINE void world_intersect(const Scene& sc, const Ray& ray, Si
 // normal_to_world (shapes.rs:272-292, groups.rs:139-164).  Identity levels are exact no-ops on
 // points and idempotent renormalisations on normals (DESIGN.md "Parent chains").
 // ---------------------------------------------------------------------------------------
+template <bool BIG = false>
 __device__ inline V3 world_to_object(const Scene& sc, uint32_t shape_xform, int parent, V3 p) {
-  int chain[RT_MAX_XF_DEPTH];
+  int chain[Lim<BIG>::kXfDepth];
   int n = 0;
   int g = parent;
   while (g >= 0) {
     int q = cst(sc.nodes)[g].next_xf;
     if (q < 0) break;
-    if (n < RT_MAX_XF_DEPTH) chain[n++] = q;
+    if (n < Lim<BIG>::kXfDepth) chain[n++] = q;
     g = cst(sc.nodes)[q].parent;
   }
   for (int i = n - 1; i >= 0; i--) p = xf_point(cst(sc.xforms)[cst(sc.nodes)[chain[i]].xform].m, p);
@@ -1670,7 +1692,7 @@ struct Pick<false, A, B> {
 template <bool COUNT, bool CULL, bool SIDE, class Source>
 __device__ inline void integrate(const Scene& sc, const RenderParams& rp, const Source& src, uint32_t remaining0,
                                  unsigned long long* queue, Counters& cn) {
-  PendingRay stack[RT_MAX_RAY_STACK];
+  PendingRay stack[Lim<SIDE>::kRayStack];
   typedef typename Pick<SIDE, XsSideList, XsList>::type List;
   List xl;
   xl.attach(sc);
@@ -1852,7 +1874,7 @@ __device__ inline void integrate(const Scene& sc, const RenderParams& rp, const 
           // the hit came through a csg list or through the wave-wide tree traversal (aux_coop), which do not carry
           // (u, v): recompute them with the ray in the triangle's space, through the same chain of transforms the
           // walk applied (same matrices in the same order => same bits)
-          Ray local = parent >= 0 ? ray_in_space_of(sc, cst(sc.nodes)[parent].next_xf, sray) : sray;
+          Ray local = parent >= 0 ? ray_in_space_of<SIDE>(sc, cst(sc.nodes)[parent].next_xf, sray) : sray;
           V3 p1, e1, e2;
           load_tri(sc, prim, p1, e1, e2);
           if (sxf) local = xf_ray(sc, sxf, local);
@@ -1868,7 +1890,7 @@ __device__ inline void integrate(const Scene& sc, const RenderParams& rp, const 
         }
         V3 point = sray.o + hit.t * sray.d;
         V3 eyev = -sray.d;
-        V3 lp = world_to_object(sc, sxf, parent, point);
+        V3 lp = world_to_object<SIDE>(sc, sxf, parent, point);
         V3 ln = local_normal_at(sc, kf, smn, smx, prim, lp, hit.u, hit.v);
         normalv = normal_to_world(sc, sxf, parent, ln);
         if (dot(normalv, eyev) < 0.f) normalv = -normalv;
@@ -1877,7 +1899,7 @@ __device__ inline void integrate(const Scene& sc, const RenderParams& rp, const 
         V3 mcolor;
         if (m.pattern >= 0) {  // pattern_at_shape at over_point (patterns.rs:79-91, world.rs:72)
           const RtPattern& pat = sc.patterns[m.pattern];
-          V3 op = world_to_object(sc, sxf, parent, over_point);
+          V3 op = world_to_object<SIDE>(sc, sxf, parent, over_point);
           V3 pp = xf_point(cst(sc.xforms)[pat.xform].m, op);
           mcolor = pattern_at(sc, pat, pp);
         } else {
@@ -2037,7 +2059,7 @@ __device__ inline void integrate(const Scene& sc, const RenderParams& rp, const 
             float cos_t = __builtin_sqrtf(1.f - sin2_t);
             V3 direction = (n_ratio * cos_i - cos_t) * normalv - n_ratio * eyev;
             float w = weight * nl * m_transparency * transmittance;
-            if (sp < RT_MAX_RAY_STACK) {
+            if (sp < Lim<SIDE>::kRayStack) {
               const V3 under_point = point - 1e-4f * normalv;
               stack[sp++] = PendingRay{Ray{under_point, direction}, w, remaining - 1u, path * 2u + 1u};
               cn.refract++;
@@ -2049,7 +2071,7 @@ __device__ inline void integrate(const Scene& sc, const RenderParams& rp, const 
         }
         if (want_reflect) {  // reflected_color (world.rs:113-125)
           float w = weight * nl * m_reflective * reflectance;
-          if (sp < RT_MAX_RAY_STACK) {
+          if (sp < Lim<SIDE>::kRayStack) {
             const V3 over_point = point + 1e-4f * normalv;
             stack[sp++] = PendingRay{Ray{over_point, reflect(sray.d, normalv)}, w, remaining - 1u, path * 2u};
             cn.reflect++;
@@ -2092,7 +2114,7 @@ __device__ inline void integrate(const Scene& sc, const RenderParams& rp, const 
 template <bool COUNT>
 __device__ __forceinline__ void simple_intersect(const Scene& sc, const Ray& ray, Sink& sink, Counters& cn) {
   if (sc.n_csg_roots) {  // world.rs:45-49
-    CsgList L;
+    CsgListT<false> L;
     L.overflow = 0;
     for (uint32_t c = 0; c < sc.n_csg_roots; c++) {
       csg_eval(sc, sc.csg_roots[c], ray, L);

@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <future>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -465,6 +466,9 @@ struct RtDeviceScene {
   std::vector<void*> allocs;
   RtContext* owner = nullptr;
   size_t aux_nodes = 0, aux_tris = 0;
+  // the world passes a capacity of the ordinary kernels (rt_device.h Lim) but not of the slow-path ones: it renders
+  // through those (need_big gives the context side lists, which is what selects them)
+  bool needs_big = false;
 };
 
 namespace {
@@ -494,10 +498,12 @@ int upload(RtContext* ctx, RtDeviceScene* ds, const T* src, size_t count, const 
 }
 
 // Reject anything that could make a kernel index out of bounds or overflow a fixed device stack.
-int validate_scene(RtContext* ctx, const RtScene* s) {
+int validate_scene(RtContext* ctx, const RtScene* s, bool* needs_big) {
   auto bad = [&](const char* what) { return fail(ctx, RT_E_SCENE, std::string("invalid scene: ") + what); };
+  *needs_big = false;
   if (s->abi_version != RT_ABI_VERSION) return fail(ctx, RT_E_ABI, "abi_version mismatch");
-  if (s->recursion_limit + 1 > RT_MAX_RAY_STACK) return bad("recursion_limit exceeds the device ray stack");
+  if (s->recursion_limit + 1 > RT_BIG_RAY_STACK) return bad("recursion_limit exceeds the device ray stack (16 levels)");
+  if (s->recursion_limit + 1 > RT_MAX_RAY_STACK) *needs_big = true;
   if (s->n_xforms < 1) return bad("xforms[0] (identity) missing");
   if (s->n_loose_shapes > s->n_shapes) return bad("n_loose_shapes > n_shapes");
   for (uint32_t i = 0; i < s->n_shapes; i++) {
@@ -521,7 +527,8 @@ int validate_scene(RtContext* ctx, const RtScene* s) {
     if (n.next_xf >= 0 && (uint32_t)n.next_xf > i) return bad("node next_xf is not an ancestor");
     if (n.next_xf >= 0 && s->nodes[n.next_xf].xform == 0) return bad("node next_xf has identity transform");
     depth[i] = (n.parent >= 0 ? depth[n.parent] : 0) + (n.xform ? 1 : 0);
-    if (depth[i] > RT_MAX_XF_DEPTH) return bad("more nested group transforms than RT_MAX_XF_DEPTH");
+    if (depth[i] > RT_BIG_XF_DEPTH) return bad("more nested group transforms than RT_BIG_XF_DEPTH (32)");
+    if (depth[i] > RT_MAX_XF_DEPTH) *needs_big = true;
   }
   for (uint32_t r = 0; r < s->n_csg_roots; r++) {
     const RtCsgRoot& root = s->csg_roots[r];
@@ -553,13 +560,15 @@ int validate_scene(RtContext* ctx, const RtScene* s) {
       }
       if (sp < nseg) return bad("csg nodes are not in post-order");
       sp = sp - nseg + 1;
-      if (sp > RT_CSG_DEPTH) return bad("csg tree deeper than RT_CSG_DEPTH");
+      if (sp > RT_BIG_CSG_DEPTH) return bad("csg tree deeper than RT_BIG_CSG_DEPTH (32)");
+      if (sp > RT_CSG_DEPTH) *needs_big = true;
     }
     if (sp != 1) return bad("csg root does not reduce to one list");
-    if (most > RT_CSG_CAP)
+    if (most > RT_BIG_CSG_CAP)
       return fail(ctx, RT_E_SCENE, "invalid scene: csg tree " + std::to_string(r) + " can give one ray " + std::to_string(most) +
-                                       " intersections, more than RT_CSG_CAP (" + std::to_string(RT_CSG_CAP) +
-                                       "); rebuild the library with a larger -DRT_CSG_CAP");
+                                       " intersections, more than RT_BIG_CSG_CAP (" + std::to_string(RT_BIG_CSG_CAP) +
+                                       "); rebuild the library with a larger -DRT_BIG_CSG_CAP");
+    if (most > RT_CSG_CAP) *needs_big = true;
   }
   for (uint32_t i = 0; i < s->n_materials; i++)
     if (s->materials[i].pattern >= (int32_t)s->n_patterns || s->materials[i].pattern < -1) return bad("material pattern");
@@ -757,6 +766,15 @@ void attach_side(const RtContext* ctx, Scene& sc) {
   sc.side = ctx->d_side;
   sc.side_cap = ctx->side_cap;
 }
+// A world (or a rt_color_at depth) beyond a capacity of the ordinary kernels renders through the slow-path ones, which a
+// context selects by holding side lists: give it some.  may_allocate false (rt_color_at_static): it must have them already.
+int need_big(RtContext* ctx, bool needed, bool may_allocate) {
+  if (!needed || ctx->side_cap) return RT_OK;
+  if (!may_allocate)
+    return fail(ctx, RT_E_LIMIT, "this world (or depth) needs the slow-path kernels, whose lists this entry point may not "
+                                 "allocate: render it once through another entry point of the same context first");
+  return grow_side(ctx);
+}
 
 }  // namespace
 
@@ -836,12 +854,14 @@ int rt_scene_create(RtContext* ctx, const RtScene* s, RtDeviceScene** out) {
     std::fprintf(stderr, "rt_scene_create: %-28s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
     t_prev = now;
   };
-  int rc = validate_scene(ctx, s);
+  bool needs_big = false;
+  int rc = validate_scene(ctx, s, &needs_big);
   stage("validate");
   if (rc != RT_OK) return rc;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   RtDeviceScene* ds = new RtDeviceScene();
   ds->owner = ctx;
+  ds->needs_big = needs_big;
   Scene& d = ds->sc;
   const RtTriGeom* tg = nullptr;
   const RtTriNormals* tn = nullptr;
@@ -851,6 +871,11 @@ int rt_scene_create(RtContext* ctx, const RtScene* s, RtDeviceScene** out) {
     return rc;                                                \
   }
   UP(d.xforms, s->xforms, (size_t)s->n_xforms)
+  // the library's own acceleration data -- auxiliary BVHs under triangle-heavy groups and the cull records of transformed
+  // groups (rt_accel.h) -- depend on the caller's arrays only: they are built on threads of their own while this one
+  // prepares and uploads the shapes (0.22 + 0.04 s of a 0.34 s call for dragons.yaml)
+  std::future<rtaccel::Result> acc_job = std::async(std::launch::async, [s] { return rtaccel::build(s); });
+  std::future<rtaccel::NodeCull> cull_job = std::async(std::launch::async, [s] { return rtaccel::build_node_cull(s); });
   {
     // device copy of the shapes: bounded analytic shapes get a cull record (rt_accel.h), its index in `prim`
     std::vector<RtShape> shapes(s->shapes, s->shapes + s->n_shapes);
@@ -924,8 +949,8 @@ int rt_scene_create(RtContext* ctx, const RtScene* s, RtDeviceScene** out) {
   {
     // the library's own acceleration data: auxiliary BVHs under triangle-heavy groups (rt_accel.h);
     // the device copy of a node carries its aux root in the slot of n_children (unused on the device)
-    rtaccel::Result acc = rtaccel::build(s);
-    stage("auxiliary trees");
+    rtaccel::Result acc = acc_job.get();
+    stage("auxiliary trees (wait)");
     std::vector<RtNode> nodes(s->nodes, s->nodes + s->n_nodes);
     // groups that hold a shape with shadow() == false somewhere below them (any-shadow search, rt_device.h)
     for (uint32_t i = 0; i < s->n_shapes; i++)
@@ -950,8 +975,8 @@ int rt_scene_create(RtContext* ctx, const RtScene* s, RtDeviceScene** out) {
     }
     // cull records of transformed groups: the record index rides in the idrun slot (0 for every transformed node)
     stage("node flags");
-    rtaccel::NodeCull nc = rtaccel::build_node_cull(s);
-    stage("subtree cull records");
+    rtaccel::NodeCull nc = cull_job.get();
+    stage("subtree cull records (wait)");
     for (uint32_t i = 0; i < s->n_nodes; i++)
       if (nc.rec_of[i] != rtaccel::kNone) {
         nodes[i].idrun = nc.rec_of[i];
@@ -1095,6 +1120,10 @@ int rt_render_device(RtContext* ctx, const RtDeviceScene* ds, const RtCamera* ca
   if (part.part >= part.n_parts) return fail(ctx, RT_E_ABI, "part >= n_parts");
   auto t0 = std::chrono::steady_clock::now();
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  {
+    int rc_big = need_big(ctx, ds->needs_big, true);
+    if (rc_big != RT_OK) return rc_big;
+  }
   hipStream_t stream = stream_ ? (hipStream_t)stream_ : ctx->stream;
   Scene sc = ds->sc;
   sc.flags = opts ? opts->flags : 0;
@@ -1177,6 +1206,10 @@ static int render_host(RtContext* ctx, const RtDeviceScene* ds, const RtCamera* 
   if (dither > RT_DITHER_BAYER_COLOR) return fail(ctx, RT_E_ABI, "unknown dither mode");
   auto t0 = std::chrono::steady_clock::now();
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  {
+    int rc_big = need_big(ctx, ds->needs_big, true);
+    if (rc_big != RT_OK) return rc_big;
+  }
   const PartInfo whole = make_part(cam, opts);
   if (whole.part >= whole.n_parts) return fail(ctx, RT_E_ABI, "part >= n_parts");
   const size_t npix = (size_t)whole.rows * cam->hsize;
@@ -1414,12 +1447,14 @@ int multi_frame_buffer(RtContext* ctx, size_t floats) {
 int multi_launch(RtContext* ctx, const RtDeviceScene* ds, const RtCamera* cam, const RtRenderOptions* opts, MultiPart& mp,
                  bool want_events) {
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc = need_big(ctx, ds->needs_big, true);
+  if (rc != RT_OK) return rc;
   Scene sc = ds->sc;
   sc.flags = opts ? opts->flags : 0;
   sc.sticky = ctx->d_sticky;
   attach_side(ctx, sc);
   RenderParams rp = make_params(opts);
-  int rc = ring_acquire(ctx, ctx->stream, &mp.slot, &mp.block);
+  rc = ring_acquire(ctx, ctx->stream, &mp.slot, &mp.block);
   if (rc != RT_OK) return rc;
   if (want_events) HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   rc = launch_part(ctx, sc, cam, rp, mp.part, mp.d_rgb, nullptr, ctx->stream, mp.block);
@@ -1736,10 +1771,14 @@ int rt_color_at(RtContext* ctx, const RtDeviceScene* ds, const RtRenderOptions* 
                 int32_t* hit_id, float* hit_uv, RtStats* stats) {
   if (!ctx || !ds || (n && (!origins || !directions))) return RT_E_ABI;
   if (ds->owner != ctx) return fail(ctx, RT_E_ABI, "scene belongs to another context");
-  if (remaining + 1 > RT_MAX_RAY_STACK) return fail(ctx, RT_E_SCENE, "remaining exceeds the device ray stack");
+  if (remaining + 1 > RT_BIG_RAY_STACK) return fail(ctx, RT_E_SCENE, "remaining exceeds the device ray stack (16 levels)");
   auto t0 = std::chrono::steady_clock::now();
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   if (n == 0) return RT_OK;
+  {
+    int rc_big = need_big(ctx, ds->needs_big || remaining + 1 > RT_MAX_RAY_STACK, true);
+    if (rc_big != RT_OK) return rc_big;
+  }
   RayBufs b;
   auto cleanup = [&]() {
     for (void* p : {(void*)b.o, (void*)b.d, (void*)b.rgb, (void*)b.t, (void*)b.uv, (void*)b.id})
@@ -1774,7 +1813,11 @@ int rt_color_at_static(RtContext* ctx, const RtDeviceScene* ds, const RtRenderOp
                        int32_t* hit_id, float* hit_uv, RtStats* stats) {
   if (!ctx || !ds || (n && (!origins || !directions))) return RT_E_ABI;
   if (ds->owner != ctx) return fail(ctx, RT_E_ABI, "scene belongs to another context");
-  if (remaining + 1 > RT_MAX_RAY_STACK) return fail(ctx, RT_E_SCENE, "remaining exceeds the device ray stack");
+  if (remaining + 1 > RT_BIG_RAY_STACK) return fail(ctx, RT_E_SCENE, "remaining exceeds the device ray stack (16 levels)");
+  {
+    int rc_big = need_big(ctx, ds->needs_big || remaining + 1 > RT_MAX_RAY_STACK, false);
+    if (rc_big != RT_OK) return rc_big;
+  }
   if (n > RT_STATIC_MAX_RAYS)
     return fail(ctx, RT_E_LIMIT, "rt_color_at_static: " + std::to_string(n) + " rays exceed RT_STATIC_MAX_RAYS (" +
                                      std::to_string(RT_STATIC_MAX_RAYS) + "); split the batch or use rt_color_at");

@@ -461,6 +461,17 @@ def test_fuzz_parts(seed, root):
     assert gpu_fuzz.run_parts(seed, log=lines.append) == 0, "\n".join(lines)
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2, 5, 8])
+def test_fuzz_few_shapes_under_area_lights(seed, root):
+    """tools/gpu_fuzz.py run_few: one to four loose shapes of any kind, some shadow-less, under a random area light --
+    the worlds that go through the direct kernel's HOIST instantiation -- against the oracle."""
+    import sys
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import gpu_fuzz
+    lines = []
+    assert gpu_fuzz.run_few(seed, log=lines.append) == 0, "\n".join(lines)
+
+
 def test_two_streams_in_flight():
     """Two frames rendered back to back on two different streams, neither synchronised in between: each launch has
     its own work queue and counter block (the ring in the context), so both canvases equal the synchronous render."""
@@ -669,21 +680,135 @@ def test_abi_error_paths():
     bad2 = abi.RtScene.from_buffer_copy(fs)
     bad2.abi_version = 99
     assert lib.rt_scene_create(raw.ctx, C.byref(bad2), C.byref(ds)) == abi.RT_E_ABI
-    # a csg tree that could give one ray more intersections than the per-ray csg list holds (RT_CSG_CAP = 32: nine
-    # cylinders, four each) is refused when the scene is created -- never discovered ray by ray
+    # a csg tree that could give one ray more intersections than even the slow-path kernels' csg list holds
+    # (RT_BIG_CSG_CAP = 256: seventy cylinders, four each) is refused when the scene is created -- never discovered ray
+    # by ray (trees between the two capacities render: test_worlds_beyond_the_ordinary_kernels_capacities)
     w = host.new_world(0)
-    cyl = [w.shape("cylinder", [("translate", 0.3 * k, 0, 0)], None, params=[-1.0, 1.0, 1.0]) for k in range(9)]
+    cyl = [w.shape("cylinder", [("translate", 0.03 * k, 0, 0)], None, params=[-1.0, 1.0, 1.0]) for k in range(70)]
     tree = w.csg(B.CSG_UNION, B.CHILD_SHAPE, cyl[0], B.CHILD_SHAPE, cyl[1])
-    for k in range(2, 9):
+    for k in range(2, 70):
         tree = w.csg(B.CSG_UNION, B.CHILD_CSG, tree, B.CHILD_SHAPE, cyl[k])
     w.add_csg(tree)
     w.add_point_light((0, 5, -5), (1, 1, 1))
-    with pytest.raises(RuntimeError, match="RT_CSG_CAP"):
+    with pytest.raises(RuntimeError, match="RT_BIG_CSG_CAP"):
+        w.device_scene()
+    w = host.new_world(0)
+    w.add_shape(w.shape("sphere", ()))
+    w.set_recursion_limit(17)
+    with pytest.raises(RuntimeError, match="recursion_limit"):
         w.device_scene()
     # a part with no rows renders nothing and succeeds (ragged: 3 rows over 8 parts)
     scene3 = Raw(scene, (8, 3))
     rgb, _, st = scene3.render(tile_h=1, n_parts=8, part=5)
     assert rgb.shape[0] == 0 and st.primary == 0
+
+
+def _deep_groups(w):
+    """a sphere and a cube under ten nested transformed groups (RT_MAX_XF_DEPTH is 6), patterned so that
+    world_to_object's chain shows in the colours"""
+    pat = w.pattern(B.PAT_CHECKER, [(0.9, 0.2, 0.2), (0.2, 0.2, 0.9)], [("scale", 0.4, 0.4, 0.4)])
+    inner = w.group([("rotate-y", 0.3)])
+    w.group_add_shape(inner, w.shape("sphere", [("translate", 0.5, 0, 0)], B.Material(pattern=pat, reflective=0.2)))
+    w.group_add_shape(inner, w.shape("cube", [("scale", 0.4, 0.4, 0.4), ("translate", -1.2, 0.2, 0)], B.Material(color=(0.3, 0.8, 0.3))))
+    g = inner
+    for k in range(9):
+        outer = w.group([("rotate-z", 0.1 * (k + 1)), ("scale", 1.05, 0.95, 1.0), ("translate", 0.05 * k, -0.03 * k, 0.02)])
+        w.group_add_child(outer, g)
+        g = outer
+    w.add_group(g)
+    w.add_shape(w.shape("plane", [("translate", 0, -2, 0)], B.Material(color=(0.8, 0.8, 0.7))))
+    w.add_point_light((-5, 8, -8), (1, 1, 1))
+
+
+def _csg_comb(w, levels):
+    """T_k = (a_k u b_k) op T_{k-1}: every level keeps a finished list waiting while the rest is evaluated, so the
+    evaluation stack grows with the levels (RT_CSG_DEPTH is 8) and so does the list (RT_CSG_CAP is 32 entries)"""
+    def ball(k, j):
+        return w.shape("sphere", [("scale", 0.5, 0.5, 0.5), ("translate", 0.35 * k - 2.0, 0.3 * j, 0.1 * k)],
+                       B.Material(color=(0.2 + 0.06 * k, 0.9 - 0.06 * k, 0.3 + 0.3 * j)))
+    tree = w.csg(B.CSG_UNION, B.CHILD_SHAPE, ball(0, 0), B.CHILD_SHAPE, ball(0, 1))
+    for k in range(1, levels):
+        pair = w.csg(B.CSG_UNION, B.CHILD_SHAPE, ball(k, 0), B.CHILD_SHAPE, ball(k, 1))
+        tree = w.csg([B.CSG_UNION, B.CSG_DIFFERENCE, B.CSG_UNION][k % 3], B.CHILD_CSG, pair, B.CHILD_CSG, tree)
+    w.add_csg(tree)
+    w.add_point_light((-5, 8, -8), (1, 1, 1))
+
+
+def _nine_cylinders(w):
+    """nine closed cylinders in one csg: up to 36 intersections of one ray with its leaves"""
+    cyl = [w.shape("cylinder", [("rotate-z", 1.2), ("translate", 0.3 * k - 1.2, 0.1 * k, 0)], B.Material(color=(0.1 * k, 0.5, 1 - 0.1 * k)),
+                   params=[-1.0, 1.0, 1.0]) for k in range(9)]
+    tree = w.csg(B.CSG_UNION, B.CHILD_SHAPE, cyl[0], B.CHILD_SHAPE, cyl[1])
+    for k in range(2, 9):
+        tree = w.csg(B.CSG_UNION if k % 2 else B.CSG_DIFFERENCE, B.CHILD_CSG, tree, B.CHILD_SHAPE, cyl[k])
+    w.add_csg(tree)
+    w.add_point_light((0, 5, -5), (1, 1, 1))
+
+
+def _mirror_hall(w):
+    """two facing mirrors and a glass ball, recursion_limit 12 (the ordinary kernels' ray stack holds 8 pending rays)"""
+    mirror = B.Material(color=(0.05, 0.05, 0.08), reflective=0.9, diffuse=0.2)
+    w.add_shape(w.shape("plane", [("rotate-x", np.pi / 2), ("translate", 0, 0, 4)], mirror))
+    w.add_shape(w.shape("plane", [("rotate-x", np.pi / 2), ("translate", 0, 0, -6)], mirror))
+    w.add_shape(w.shape("plane", [("translate", 0, -1, 0)], B.Material(color=(0.7, 0.6, 0.5))))
+    w.add_shape(w.shape("sphere", [("translate", 0.4, 0, 0)], B.Material(color=(0.8, 0.1, 0.1), transparency=0.6, reflective=0.3,
+                                                                          refractive_index=1.5, diffuse=0.3)))
+    w.set_recursion_limit(12)
+    w.add_point_light((-3, 6, -4), (1, 1, 1))
+
+
+@pytest.mark.parametrize("build", [_deep_groups, _csg_comb, _nine_cylinders, _mirror_hall])
+def test_worlds_beyond_the_ordinary_kernels_capacities(build):
+    """Where the reference is unbounded the ordinary kernels have fixed capacities (rt_device.h Lim): six nested group
+    transforms, a csg evaluation stack of 8 and list of 32, 8 pending rays.  A world that passes one renders through the
+    slow-path instantiation (32 / 32 / 256 / 17) instead of being refused, and equals the oracle like any other."""
+    def make(w):
+        if build is _csg_comb:
+            build(w, 12)
+        else:
+            build(w)
+        return w
+    cam = B.Camera(200, 120, 0.9, (0.5, 1.5, -6), (0, 0, 0), (0, 1, 0))
+    gw = make(host.new_world(0))
+    g = gw.render(cam, aux=True)
+    r = make(_oracle().new_world()).render(cam, aux=True)
+    check(g, r, build.__name__)
+    assert r.hit_mask.mean() > 0.02
+    # ... and through rt_color_at, which shares the context (and so the kernels) with the frame above
+    rng = np.random.RandomState(3)
+    o = rng.uniform(-3, 3, size=(5000, 3)).astype(np.float32) + np.array([0, 1, -6], dtype=np.float32)
+    d = -o + rng.uniform(-1.5, 1.5, size=(5000, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    remaining = 12 if build is _mirror_hall else 4
+    grgb, gt, gid, _ = gw.color_at(o, d, remaining)
+    rrgb, rt, rid, _ = make(_oracle().new_world()).color_at(o, d, remaining)
+    assert np.array_equal(gid, rid)
+    hit = rid >= 0
+    assert np.array_equal(gt[hit].view(np.uint32), rt[hit].view(np.uint32))
+    dd = np.abs(to_u8(grgb).astype(int) - to_u8(rrgb).astype(int)).max(axis=1)
+    assert (dd <= 1).mean() >= LSB_FRACTION
+
+
+def test_color_at_deeper_than_the_ordinary_ray_stack():
+    """rt_color_at with remaining = 10 on a world that fits the ordinary kernels: the call moves the context to the
+    slow-path kernels (17 pending rays) and equals the oracle."""
+    def world(w):
+        _mirror_hall(w)
+        w.set_recursion_limit(4)
+        return w
+    rng = np.random.RandomState(4)
+    o = rng.uniform(-2, 2, size=(3000, 3)).astype(np.float32)
+    d = rng.normal(size=(3000, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    gw, ow = world(host.new_world(0)), world(_oracle().new_world())
+    for remaining in (7, 10, 16):
+        grgb, gt, gid, _ = gw.color_at(o, d, remaining)
+        rrgb, rt, rid, _ = ow.color_at(o, d, remaining)
+        assert np.array_equal(gid, rid) and np.array_equal(gt[rid >= 0].view(np.uint32), rt[rid >= 0].view(np.uint32))
+        dd = np.abs(to_u8(grgb).astype(int) - to_u8(rrgb).astype(int)).max(axis=1)
+        assert (dd <= 1).mean() >= LSB_FRACTION, remaining
+    with pytest.raises(RuntimeError, match="ray stack"):
+        gw.color_at(o[:4], d[:4], 17)
 
 
 def test_world_without_lights_is_black():

@@ -81,7 +81,11 @@ def test_static_entry_point_rejects_what_does_not_fit():
     rc = _call(lib.rt_color_at_static, ctx, ds, o, d, 4)[0]
     assert rc == abi.RT_E_LIMIT and b"RT_STATIC_MAX_RAYS" in lib.rt_last_error(ctx)
     assert _call(lib.rt_color_at_static, ctx, ds, o[:0], d[:0], 4)[0] == abi.RT_OK  # nothing to do
-    assert _call(lib.rt_color_at_static, ctx, ds, o[:10], d[:10], 99)[0] == abi.RT_E_SCENE  # deeper than the ray stack
+    assert _call(lib.rt_color_at_static, ctx, ds, o[:10], d[:10], 99)[0] == abi.RT_E_SCENE  # deeper than any ray stack
+    # deeper than the ordinary kernels' ray stack: the slow-path kernels keep lists in device memory that this entry
+    # point may not allocate
+    rc = _call(lib.rt_color_at_static, ctx, ds, o[:10], d[:10], 10)[0]
+    assert rc == abi.RT_E_LIMIT and b"may not" in lib.rt_last_error(ctx)
     got, want = _call(lib.rt_color_at_static, ctx, ds, o[:10], d[:10], 4), _call(lib.rt_color_at, ctx, ds, o[:10], d[:10], 4)
     assert got[0] == abi.RT_OK
     _same(got, want)

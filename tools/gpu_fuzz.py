@@ -223,6 +223,57 @@ def run_frame(seed, log=print):
     return 0
 
 
+def few_world(w, rng):
+    """One to four loose shapes of any kind (any of them shadow-less), nothing else, under an area light of up to 4x4
+    cells or a point light: the worlds whose shadow rays keep their origin in every shape's space and meet the
+    shadow-casting shapes first (rt_device.h hoisted_is_shadowed; area lights only, rt_hip.hip launch_part)."""
+    from raytracer_amd import builder as B
+    n = int(rng.randint(1, 5))
+    for i in range(n):
+        kind = ["sphere", "cube", "cylinder", "cone", "plane"][int(rng.randint(5))]
+        params = None
+        if kind in ("cylinder", "cone"):
+            lo = rng.uniform(-2, 0)
+            params = [lo, lo + rng.uniform(0.5, 3), float(rng.randint(2))]
+        ops = [("scale", *rng.uniform(0.3, 3.0, 3)), ("rotate-x", rng.uniform(-3, 3)), ("rotate-z", rng.uniform(-3, 3)),
+               ("translate", *rng.uniform(-4, 4, 3))]
+        if kind == "plane":
+            ops = [("rotate-x", rng.uniform(-0.3, 0.3)), ("translate", 0, rng.uniform(-6, -2), 0)]
+        if rng.randint(4) == 0:
+            ops = []  # identity transform: the origin is used as it is
+        m = B.Material(color=tuple(rng.uniform(0, 1, 3)), reflective=0.5 * (rng.randint(3) == 0),
+                       transparency=0.7 * (rng.randint(4) == 0), refractive_index=float(rng.choice([1.0, 1.5])))
+        w.add_shape(w.shape(kind, ops, m, shadow=bool(rng.randint(3)), params=params))
+    corner = tuple(rng.uniform(-8, 8, 3) + np.array([0, 10, 0]))
+    w.add_area_light(corner, tuple(rng.uniform(-3, 3, 3)), int(rng.randint(1, 5)), tuple(rng.uniform(-3, 3, 3)),
+                     int(rng.randint(1, 5)), tuple(rng.uniform(0.3, 1, 3)))
+    if rng.randint(3) == 0:
+        w.add_point_light(tuple(rng.uniform(-10, 10, 3)), (0.3, 0.3, 0.3))
+
+
+def run_few(seed, log=print):
+    """A few_world frame against the oracle (bars of tests/test_gpu_parity.py check)."""
+    from raytracer_amd import builder as B
+    from test_gpu_parity import check
+    rng = np.random.RandomState(11000 + seed)
+    gw, ow = host.new_world(0), oracle.new_world()
+    few_world(gw, np.random.RandomState(seed))
+    few_world(ow, np.random.RandomState(seed))
+    eye = rng.uniform(-9, 9, 3)
+    cam = B.Camera(int(rng.randint(17, 200)), int(rng.randint(9, 120)), float(rng.uniform(0.5, 1.6)), tuple(eye),
+                   tuple(rng.uniform(-2, 2, 3)), (0, 1, 0))
+    ro = B.RenderOptions(jitter_mode=B.JITTER_COUNTER if seed % 3 else B.JITTER_CONST, seed=seed)
+    g = gw.render(cam, ro, aux=True)
+    r = ow.render(cam, ro, aux=True)
+    try:
+        check(g, r, f"few seed {seed}", one_light=int(gw.flatten().n_lights) == 1)
+    except AssertionError as e:
+        log(f"few seed {seed} {cam.hsize}x{cam.vsize}: FAIL {e}")
+        return 1
+    log(f"few seed {seed} {cam.hsize}x{cam.vsize}: ok, hits {r.hit_mask.mean():.2f}, shadow rays {r.stats['shadow']}")
+    return 0
+
+
 class _FuzzScene:
     """What tests/test_gpu_parity.py Raw needs of a scene: build(world) and camera(w, h)."""
 
@@ -267,6 +318,11 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "parts":
         first, count = int(sys.argv[2]), int(sys.argv[3])
         bad = sum(run_parts(seed, log=lambda m: print(m, flush=True)) for seed in range(first, first + count))
+        print("failures:", bad)
+        sys.exit(1 if bad else 0)
+    if len(sys.argv) > 1 and sys.argv[1] == "few":
+        first, count = int(sys.argv[2]), int(sys.argv[3])
+        bad = sum(run_few(seed, log=lambda m: print(m, flush=True)) for seed in range(first, first + count))
         print("failures:", bad)
         sys.exit(1 if bad else 0)
     if len(sys.argv) > 1 and sys.argv[1] == "frames":
