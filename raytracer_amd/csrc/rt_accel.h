@@ -40,7 +40,9 @@
 #pragma once
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -384,6 +386,15 @@ inline bool box_inside(const RtNode& c, const RtNode& p) {
 inline Result build(const RtScene* s) {
   Result r;
   const uint32_t nn = s->n_nodes;
+  // RT_TIMING=1 in the environment: stage times on stderr
+  const bool timing = std::getenv("RT_TIMING") != nullptr;
+  auto t_prev = std::chrono::steady_clock::now();
+  auto stage = [&](const char* what) {
+    if (!timing) return;
+    auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "rt_accel build: %-34s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+    t_prev = now;
+  };
   r.root_of.assign(nn, kNone);
   r.gate_next.assign(nn, kNone);
   if (nn == 0) return r;
@@ -467,6 +478,7 @@ inline Result build(const RtScene* s) {
       canon[t] = slots[i];
     }
   }
+  stage("roots, canonical triangles");
   std::vector<Inst> inst(roots.size());
   for (size_t j = 0; j < roots.size(); j++) {
     Inst& I = inst[j];
@@ -507,6 +519,7 @@ inline Result build(const RtScene* s) {
         inst[j].same_as = q;
         break;
       }
+  stage("instances");
   struct Out {
     std::vector<Node> nodes;
     std::vector<Tri> tris;
@@ -543,6 +556,7 @@ inline Result build(const RtScene* s) {
   for (unsigned t = 1; t < nt; t++) th.emplace_back(work, t);
   work(0);
   for (auto& t : th) t.join();
+  stage("binary trees (threads)");
   // the trees, without their headers; leaf triangles made relative to the instance
   for (size_t j : todo) {
     if (!outs[j].ok) continue;
@@ -601,6 +615,7 @@ inline Result build(const RtScene* s) {
       r.tris.push_back(t);
     }
   }
+  stage("fold to 4-wide nodes, leaves");
   // one entry record per root
   for (size_t j = 0; j < roots.size(); j++) {
     const Out& o = outs[inst[j].same_as];
@@ -627,6 +642,7 @@ inline Result build(const RtScene* s) {
         r.gate_next[c] = p;
     }
   }
+  stage("entry records, gate chains");
   return r;
 }
 
