@@ -51,6 +51,16 @@ struct Lim {
 #define RT_SCENE_SHADOW_TWO_PASS 0x4u // Scene::props: shadow-less shapes exist AND auxiliary BVHs exist: find F first, then any occluder
 #define RT_SCENE_SHAPE_CULL 0x10u   // Scene::props: some shapes have cull records (k_render_jobs<., true>)
 #define RT_SCENE_AREA_LIGHT 0x8u   // Scene::props: some area light takes more than one sample
+#define RT_SCENE_HAS_PATTERN 0x80u  // Scene::props: some material has a pattern
+#define RT_SCENE_OTHER_LIGHT 0x100u // Scene::props: some light is not a point light
+// What a job-loop kernel is compiled with (integrate<.., FEAT>, world_intersect<.., FEAT>): the launch picks the
+// instantiation with the fewest features that still covers the scene (rt_hip.hip jobs_kernel)
+#define RT_F_CSG 1u      // csg trees (world.rs:45-49)
+#define RT_F_COLLECT 2u  // the n1/n2 pass and its lists: some refractive index is not 1
+#define RT_F_PATTERN 4u  // pattern evaluation
+#define RT_F_AREA 8u     // lights other than point lights
+#define RT_F_GROUPS 16u  // the reference walk over groups and the auxiliary trees below them
+#define RT_F_ALL 31u
 #define RT_SCENE_RI_ALL_ONE 0x2u   // Scene::props: every material has refractive_index == 1 (n1 = n2 = 1 always)
 
 namespace rtd {
@@ -442,6 +452,13 @@ struct XsList {
     t[c] = tt;
     s[c] = ss;
   }
+};
+// No list at all: the kernels without RT_F_COLLECT (worlds in which every refractive index is 1 never walk n1/n2 lists)
+struct XsNone {
+  static constexpr bool kBig = false;
+  __device__ __forceinline__ void attach(const Scene&) {}
+  __device__ __forceinline__ int capacity() const { return 0; }
+  __device__ __forceinline__ void put(int, float, uint32_t) {}
 };
 // A lane's side lists: [xs t | xs s | containers], side_cap entries each.
 enum { SIDE_XS_T = 0, SIDE_XS_S = 1, SIDE_CONTAINERS = 2, SIDE_LISTS = 3 };
@@ -1176,12 +1193,12 @@ __device__ inline Ray ray_in_space_of(const Scene& sc, int xf_node, const Ray& w
 #ifndef RT_WI_INLINE
 #define RT_WI_INLINE inline
 #endif
-template <bool COUNT, bool CULL, class Sink>
+template <bool COUNT, bool CULL, uint32_t FEAT = RT_F_ALL, class Sink>
 __device__ RT_WI_INLINE void world_intersect(const Scene& sc, const Ray& ray, Sink& sink, Counters& cn,
                                              const bool active = true) {
   // `active` false: this lane has no ray to trace but still takes part in the wave-wide votes of the walk
   // csgs first (world.rs:45-49)
-  if (sc.n_csg_roots && active) {
+  if ((FEAT & RT_F_CSG) && sc.n_csg_roots && active) {
     CsgListT<Sink::kBig> L;
     L.overflow = 0;
     for (uint32_t c = 0; c < sc.n_csg_roots; c++) {
@@ -1192,7 +1209,7 @@ __device__ RT_WI_INLINE void world_intersect(const Scene& sc, const Ray& ray, Si
     cn.overflow += L.overflow;
   }
   // groups (world.rs:51-54)
-  {
+  if constexpr ((FEAT & RT_F_GROUPS) != 0u) {
     Ray cur = ray;
     uint32_t leave_at = 0xFFFFFFFFu;  // first node outside the innermost transformed subtree this lane is in
     const bool prune = !(sc.flags & RT_RENDER_NO_PRUNE);
@@ -1260,7 +1277,7 @@ __device__ RT_WI_INLINE void world_intersect(const Scene& sc, const Ray& ray, Si
       if ((flags & RT_NODE_AUX) && !(sc.flags & RT_RENDER_NO_ACCEL)) {  // wave-uniform
         RT_T0(ta);
         bool want = descend;
-        if (want && sink.mode == SINK_COLLECT) {  // the n1/n2 pass keeps a per-lane list: its own traversal
+        if ((FEAT & RT_F_COLLECT) && want && sink.mode == SINK_COLLECT) {  // the n1/n2 pass keeps a per-lane list: its own traversal
           if (aux_intersect<COUNT>(sc, i, w3.w, cur, sink, cn)) descend = false;
           want = false;
         }
@@ -1689,11 +1706,15 @@ struct Pick<false, A, B> {
   typedef B type;
 };
 // SIDE: the n1/n2 lists live in the context's side lists (see XsList)
-template <bool COUNT, bool CULL, bool SIDE, class Source>
+// FEAT: what the scene needs of RT_F_* (rt_hip.hip jobs_kernel picks the instantiation; dragons.yaml needs
+// RT_F_GROUPS alone, cover.yaml RT_F_COLLECT alone): the code of everything else -- csg evaluation, the n1/n2 collect pass and
+// its lists, pattern evaluation with its libm calls, the area-light sample loops -- is not in the kernel at all.  The
+// job loop is ~14 000 instructions, more than the instruction cache of a pair of CUs holds.
+template <bool COUNT, bool CULL, bool SIDE, uint32_t FEAT = RT_F_ALL, class Source>
 __device__ inline void integrate(const Scene& sc, const RenderParams& rp, const Source& src, uint32_t remaining0,
                                  unsigned long long* queue, Counters& cn) {
   PendingRay stack[Lim<SIDE>::kRayStack];
-  typedef typename Pick<SIDE, XsSideList, XsList>::type List;
+  typedef typename Pick<!(FEAT & RT_F_COLLECT), XsNone, typename Pick<SIDE, XsSideList, XsList>::type>::type List;
   List xl;
   xl.attach(sc);
   Park pk{threadIdx.x};
@@ -1822,7 +1843,7 @@ __device__ inline void integrate(const Scene& sc, const RenderParams& rp, const 
     const bool active = st != ST_IDLE;
     // ---------------- the one traversal ----------------
     SinkT<List> sink;
-    if (job == JOB_COLLECT)
+    if ((FEAT & RT_F_COLLECT) && job == JOB_COLLECT)
       sink.init_collect(&xl, hit_t);
     else if (job == JOB_SHADOW && (sc.props & RT_SCENE_HAS_NOSHADOW) && !(sc.props & RT_SCENE_SHADOW_TWO_PASS)) {
       sink.init_closest();  // small scene with shadow-less shapes: one closest-hit pass, capped at the light
@@ -1835,7 +1856,7 @@ __device__ inline void integrate(const Scene& sc, const RenderParams& rp, const 
       sink.init_closest();
     const uint32_t work0 = COUNT ? cn.node_visits + cn.aux_tests + cn.tri_tests + cn.shape_tests : 0u;
     RT_T0(tw);
-    world_intersect<COUNT, CULL>(sc, tray, sink, cn, active);
+    world_intersect<COUNT, CULL, FEAT>(sc, tray, sink, cn, active);
     RT_TACC(t_world, tw);
     // parked values are re-read after the traversal, not carried through it in registers: the pointer is laundered
     // so that loads below cannot be forwarded from the stores above (a "memory" clobber would do the same but also
@@ -1870,7 +1891,7 @@ __device__ inline void integrate(const Scene& sc, const RenderParams& rp, const 
         mat_id = w0.z;
         int parent = (int)w0.w;
         float smn = __uint_as_float(w1.z), smx = __uint_as_float(w1.w);
-        if ((kf & RT_SHAPE_KIND_MASK) == RT_SMOOTH_TRIANGLE && hit.u != hit.u) {
+        if ((FEAT & (RT_F_CSG | RT_F_GROUPS)) && (kf & RT_SHAPE_KIND_MASK) == RT_SMOOTH_TRIANGLE && hit.u != hit.u) {
           // the hit came through a csg list or through the wave-wide tree traversal (aux_coop), which do not carry
           // (u, v): recompute them with the ray in the triangle's space, through the same chain of transforms the
           // walk applied (same matrices in the same order => same bits)
@@ -1897,7 +1918,7 @@ __device__ inline void integrate(const Scene& sc, const RenderParams& rp, const 
         V3 over_point = point + 1e-4f * normalv;
         const RtMaterial RT_CONST_AS& m = cst(sc.materials)[mat_id];
         V3 mcolor;
-        if (m.pattern >= 0) {  // pattern_at_shape at over_point (patterns.rs:79-91, world.rs:72)
+        if ((FEAT & RT_F_PATTERN) && m.pattern >= 0) {  // pattern_at_shape at over_point (patterns.rs:79-91, world.rs:72)
           const RtPattern& pat = sc.patterns[m.pattern];
           V3 op = world_to_object<SIDE>(sc, sxf, parent, over_point);
           V3 pp = xf_point(cst(sc.xforms)[pat.xform].m, op);
@@ -1933,7 +1954,7 @@ __device__ inline void integrate(const Scene& sc, const RenderParams& rp, const 
       V3 effective = mulc(pk_ld3(pk, PK_MCOLOR), lcol);
       V3 ambient = m_ambient * effective;
       V3 surface_sum = pk_ld3(pk, PK_SURFACE);
-      if (L.kind == RT_LIGHT_POINT) {
+      if (!(FEAT & RT_F_AREA) || L.kind == RT_LIGHT_POINT) {
         V3 lpos = v3(L.position[0], L.position[1], L.position[2]);
         float intensity = shadowed ? 0.f : 1.f;  // lights.rs:50-56
         V3 diffuse = v3(0.f, 0.f, 0.f), specular = v3(0.f, 0.f, 0.f);
@@ -1972,7 +1993,7 @@ __device__ inline void integrate(const Scene& sc, const RenderParams& rp, const 
           st = ST_NEXT_LIGHT;
         }
       }
-    } else {  // JOB_COLLECT
+    } else if constexpr ((FEAT & RT_F_COLLECT) != 0u) {  // JOB_COLLECT
       cn.overflow += sink.overflow();
       refractive_indices_of(sc, xl, sink.count(), hit_t, hit_shape, n1, n2);
       st = ST_SECONDARY;
@@ -1984,7 +2005,7 @@ __device__ inline void integrate(const Scene& sc, const RenderParams& rp, const 
         if (li < sc.n_lights) {
           const RtLight RT_CONST_AS& L = cst(sc.lights)[li];
           V3 lpos;
-          if (L.kind == RT_LIGHT_POINT) {
+          if (!(FEAT & RT_F_AREA) || L.kind == RT_LIGHT_POINT) {
             lpos = v3(L.position[0], L.position[1], L.position[2]);
           } else {
             uint32_t u = sample / L.vsteps, v = sample % L.vsteps;  // u outer, v inner (lights.rs:125-126)
@@ -2010,7 +2031,7 @@ __device__ inline void integrate(const Scene& sc, const RenderParams& rp, const 
         bool want_reflect = m.reflective != 0.f, want_refract = m.transparency != 0.f;
         if (remaining == 0 || sc.n_lights == 0 || (!want_reflect && !want_refract)) {
           st = ST_NEXT_RAY;
-        } else if (want_refract && !(sc.props & RT_SCENE_RI_ALL_ONE)) {
+        } else if ((FEAT & RT_F_COLLECT) && want_refract && !(sc.props & RT_SCENE_RI_ALL_ONE)) {
           tray = Ray{pk_ld3(pk, PK_SRAY_O), pk_ld3(pk, PK_SRAY_D)};
           job = JOB_COLLECT;
           st = ST_TRACE;

@@ -197,8 +197,14 @@ struct PixelSource {
     write_colour<COUNT>(*sc, o, (size_t)(item >> 16) * cam.hsize + (item & 0xFFFFu), col, (float)work, ws, wc);
   }
 };
-template <bool COUNT, bool CULL, bool SIDE = false>
-__global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAVES_PER_EU, RT_WAVES_PER_EU)))
+// FEAT: the RT_F_* the kernel is compiled with (jobs_kernel below picks one).  Kernels without the group walk are not
+// bound by its registers: RT_FLAT_WAVES_PER_EU
+#ifndef RT_FLAT_WAVES_PER_EU
+#define RT_FLAT_WAVES_PER_EU 4  // 103-116 VGPRs without the walk: four waves per SIMD without a spill
+#endif
+#define RT_JOBS_WAVES ((FEAT & RT_F_GROUPS) ? RT_WAVES_PER_EU : RT_FLAT_WAVES_PER_EU)
+template <bool COUNT, bool CULL, bool SIDE = false, uint32_t FEAT = RT_F_ALL>
+__global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_JOBS_WAVES, RT_JOBS_WAVES)))
 void k_render_jobs(Scene sc, RtCamera cam, RenderParams rp, PartInfo part, PixelOut o, unsigned long long* counters) {
 #ifdef RT_PHASE_TIMERS
   const uint64_t t_pixel0 = __builtin_readcyclecounter();
@@ -206,7 +212,7 @@ void k_render_jobs(Scene sc, RtCamera cam, RenderParams rp, PartInfo part, Pixel
 #endif
   PixelSource<COUNT> src{&sc, cam, part, o, (cam.hsize + 8u * RT_SUPER - 1u) / (8u * RT_SUPER), (part.rows + 8u * RT_SUPER - 1u) / (8u * RT_SUPER)};
   Counters cn = {};
-  integrate<COUNT, CULL, SIDE>(sc, rp, src, sc.recursion_limit, counters + RT_QUEUE_SLOT, cn);
+  integrate<COUNT, CULL, SIDE, FEAT>(sc, rp, src, sc.recursion_limit, counters + RT_QUEUE_SLOT, cn);
 #ifdef RT_PHASE_TIMERS
   if ((threadIdx.x & 63) == 0) {
     atomicAdd(counters + 14, (unsigned long long)(__builtin_readcyclecounter() - t_pixel0));
@@ -778,6 +784,36 @@ int need_big(RtContext* ctx, bool needed, bool may_allocate) {
 
 }  // namespace
 
+// The job loop with everything in it is ~14 000 instructions, more than the instruction cache of a pair of CUs holds,
+// and what a scene does not use still costs: registers, scratch, fetches around the dead code.  The sample scenes of
+// the reference use one feature each (dragons: groups; cover: refraction; csg: csg; checkered_*, basic_scene: patterns),
+// so there is one instantiation per single feature and the complete one for every mixture.  RT_NO_LEAN=1 in the
+// environment takes the complete one always (A/B timing, tests).
+static uint32_t scene_features(const Scene& sc) {
+  uint32_t f = 0;
+  if (sc.n_csg_roots) f |= RT_F_CSG;
+  if (!(sc.props & RT_SCENE_RI_ALL_ONE)) f |= RT_F_COLLECT;
+  if (sc.props & RT_SCENE_HAS_PATTERN) f |= RT_F_PATTERN;
+  if (sc.props & RT_SCENE_OTHER_LIGHT) f |= RT_F_AREA;
+  if (sc.n_nodes) f |= RT_F_GROUPS;
+  return f;
+}
+typedef void (*JobsKernel)(Scene, RtCamera, RenderParams, PartInfo, PixelOut, unsigned long long*);
+struct JobsPick {
+  JobsKernel kern;
+  uint32_t blocks_per_cu;  // resident 256-thread blocks per CU = the kernel's waves per SIMD
+};
+template <bool CULL>
+static JobsPick jobs_kernel(uint32_t need) {
+  const bool complete = std::getenv("RT_NO_LEAN") != nullptr;
+  if (complete) return {k_render_jobs<false, CULL>, RT_BLOCKS_PER_CU};
+  if (!(need & ~RT_F_PATTERN)) return {k_render_jobs<false, CULL, false, RT_F_PATTERN>, RT_FLAT_WAVES_PER_EU};
+  if (!(need & ~RT_F_COLLECT)) return {k_render_jobs<false, CULL, false, RT_F_COLLECT>, RT_FLAT_WAVES_PER_EU};
+  if (!(need & ~RT_F_CSG)) return {k_render_jobs<false, CULL, false, RT_F_CSG>, RT_FLAT_WAVES_PER_EU};
+  if (!(need & ~RT_F_GROUPS)) return {k_render_jobs<false, CULL, false, RT_F_GROUPS>, RT_BLOCKS_PER_CU};
+  return {k_render_jobs<false, CULL>, RT_BLOCKS_PER_CU};
+}
+
 extern "C" {
 
 uint32_t rt_abi_version(void) { return RT_ABI_VERSION; }
@@ -962,6 +998,10 @@ int rt_scene_create(RtContext* ctx, const RtScene* s, RtDeviceScene** out) {
     bool ri_one = true;
     for (uint32_t i = 0; i < s->n_materials; i++) ri_one = ri_one && s->materials[i].refractive_index == 1.0f;
     if (ri_one) d.props |= RT_SCENE_RI_ALL_ONE;
+    for (uint32_t i = 0; i < s->n_materials; i++)
+      if (s->materials[i].pattern >= 0) d.props |= RT_SCENE_HAS_PATTERN;
+    for (uint32_t i = 0; i < s->n_lights; i++)
+      if (s->lights[i].kind != RT_LIGHT_POINT) d.props |= RT_SCENE_OTHER_LIGHT;
     for (uint32_t i = 0; i < s->n_lights; i++)
       if (s->lights[i].kind == RT_LIGHT_AREA && s->lights[i].usteps * s->lights[i].vsteps > 1) d.props |= RT_SCENE_AREA_LIGHT;
     if ((d.props & RT_SCENE_HAS_NOSHADOW) && !acc.nodes.empty()) d.props |= RT_SCENE_SHADOW_TWO_PASS;
@@ -1091,13 +1131,14 @@ static int launch_part(RtContext* ctx, const Scene& sc, const RtCamera* cam, con
     if (super_items >= 0xFFFFFFFFull) return fail(ctx, RT_E_ABI, "image too large");
     // ... and a lane keeps its pixel as (row << 16 | column) (PixelSource::start)
     if (cam->hsize > 0xFFFFu || part.rows > 0xFFFFu) return fail(ctx, RT_E_ABI, "image too large (65535 pixels a side)");
-    const uint32_t blocks = (uint32_t)std::min<uint64_t>((items + RT_BLOCK - 1) / RT_BLOCK, (uint64_t)ctx->n_cus * RT_BLOCKS_PER_CU);
     const bool cull = (sc.props & RT_SCENE_SHAPE_CULL) != 0;  // the scene has cull records (rt_scene_create)
-    auto kern = count ? (cull ? k_render_jobs<true, true> : k_render_jobs<true, false>)
-                      : (cull ? k_render_jobs<false, true> : k_render_jobs<false, false>);
+    JobsPick pick = count ? (cull ? JobsPick{k_render_jobs<true, true>, RT_BLOCKS_PER_CU} : JobsPick{k_render_jobs<true, false>, RT_BLOCKS_PER_CU})
+                          : (cull ? jobs_kernel<true>(scene_features(sc)) : jobs_kernel<false>(scene_features(sc)));
     // a context with side lists: the one instantiation that keeps the n1/n2 lists there (it counts work and tests cull
     // records whether asked to or not: it is the slow path, and one kernel instead of four keeps the build short)
-    if (sc.side_cap) kern = k_render_jobs<true, true, true>;
+    if (sc.side_cap) pick = JobsPick{k_render_jobs<true, true, true>, RT_BLOCKS_PER_CU};
+    const auto kern = pick.kern;
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>((items + RT_BLOCK - 1) / RT_BLOCK, (uint64_t)ctx->n_cus * pick.blocks_per_cu);
     // A scene of a few shapes has cheap tiles throughout, and its frame time is the queue's atomics: draw up to
     // RT_LIGHT_SCENE_CHUNK tiles at a time, as long as every wave still gets RT_LIGHT_SCENE_DRAWS draws
     // (integrate's refill).

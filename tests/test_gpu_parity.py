@@ -228,6 +228,22 @@ def test_parts_reassemble_at_4k(name, size):
         assert rays == st.primary + st.shadow + st.reflect + st.refract
 
 
+@pytest.mark.parametrize("name", ["dragons", "cover", "csg", "checkered_cube", "basic_scene", "space_teapot"])
+def test_single_feature_kernels_change_nothing(name, obj_files, monkeypatch):
+    """The launch picks the job-loop kernel compiled with the fewest features that cover the scene (rt_hip.hip
+    jobs_kernel: groups / n1-n2 lists / csg / patterns, one each; the group-less ones at four waves per SIMD).  With
+    RT_NO_LEAN in the environment every scene goes through the complete kernel: same bytes, same ids, same rays."""
+    from raytracer_amd import synth
+    meshes = {"dragon.obj": synth.synth_dragon(220, 220)} if name == "dragons" else None
+    scene = Scene.from_file(scene_path(name), obj_files=obj_files, meshes=meshes)
+    raw = Raw(scene, (2563, 1437))
+    lean, lids, ls = raw.render()
+    monkeypatch.setenv("RT_NO_LEAN", "1")
+    full, fids, fs = raw.render()
+    assert np.array_equal(lean.view(np.uint32), full.view(np.uint32)) and np.array_equal(lids, fids)
+    assert (ls.primary, ls.shadow, ls.reflect, ls.refract, ls.overflow) == (fs.primary, fs.shadow, fs.reflect, fs.refract, 0)
+
+
 @pytest.mark.parametrize("size", [(1, 1), (7, 3), (65, 9), (130, 67)])
 def test_ragged_frames_match_oracle(size):
     """Frames that are not whole 8x8 tiles (the work queue hands out items outside the image) and ragged parts:
