@@ -265,6 +265,10 @@ typedef struct {
   void* owner;
 } RtAccelView;
 int rt_accel_build(const RtScene*, RtAccelView* out);
+/* The same view with the trees of 16384 triangles and more built on the context's GPU, which is how rt_scene_create
+ * builds them (raytracer_amd/csrc/rt_accel_device.h: the same splits, boxes and leaves as the host builder's; tests
+ * compare the two views). rt_last_error says so when the device builder declined a tree and the host built it. */
+int rt_accel_build_device(RtContext*, const RtScene*, RtAccelView* out);
 void rt_accel_free(RtAccelView*);
 
 /* Number of rows a (camera, options) pair renders on this part (for buffer sizing). */

@@ -100,7 +100,7 @@ AUX_TRI = np.dtype([("p1", "<f4", 3), ("shape", "<u4"), ("e1", "<f4", 3), ("owne
                     ("kind_flags", "<u4")])
 assert AUX_NODE.itemsize == 128 and AUX_TRI.itemsize == 48
 
-EXPORTS = ["rt_host_alloc", "rt_host_free", "rt_accel_build", "rt_accel_free", "rt_abi_version", "rt_context_create", "rt_context_destroy", "rt_last_error", "rt_scene_create",
+EXPORTS = ["rt_host_alloc", "rt_host_free", "rt_accel_build", "rt_accel_build_device", "rt_accel_free", "rt_abi_version", "rt_context_create", "rt_context_destroy", "rt_last_error", "rt_scene_create",
            "rt_scene_destroy", "rt_part_rows", "rt_render", "rt_render_u8", "rt_canvas_to_u8_device", "rt_render_device", "rt_check", "rt_color_at", "rt_color_at_static", "rt_device_count", "rt_render_multi",
            "rt_render_multi_device"]
 
@@ -116,6 +116,7 @@ def declare(lib: C.CDLL) -> None:
     lib.rt_host_alloc.restype, lib.rt_host_alloc.argtypes = P, [P, C.c_uint64]
     lib.rt_host_free.restype, lib.rt_host_free.argtypes = None, [P, P]
     lib.rt_accel_build.restype, lib.rt_accel_build.argtypes = C.c_int, [C.POINTER(RtScene), C.POINTER(RtAccelView)]
+    lib.rt_accel_build_device.restype, lib.rt_accel_build_device.argtypes = C.c_int, [C.c_void_p, C.POINTER(RtScene), C.POINTER(RtAccelView)]
     lib.rt_accel_free.restype, lib.rt_accel_free.argtypes = None, [C.POINTER(RtAccelView)]
     lib.rt_part_rows.restype, lib.rt_part_rows.argtypes = C.c_uint32, [C.POINTER(RtCamera), C.POINTER(RtRenderOptions)]
     lib.rt_render.restype = C.c_int
@@ -150,10 +151,11 @@ def _view(ptr, count, dtype):
     return np.frombuffer(buf, dtype=dtype, count=count).copy()
 
 
-def accel_arrays(lib: C.CDLL, s: RtScene) -> dict:
-    """The auxiliary BVHs of a flattened scene as numpy arrays (copies)."""
+def accel_arrays(lib: C.CDLL, s: RtScene, ctx=None) -> dict:
+    """The auxiliary BVHs of a flattened scene as numpy arrays (copies); with a context: the big trees built on its
+    GPU (rt_accel_build_device), as rt_scene_create builds them."""
     v = RtAccelView()
-    rc = lib.rt_accel_build(C.byref(s), C.byref(v))
+    rc = lib.rt_accel_build_device(ctx, C.byref(s), C.byref(v)) if ctx else lib.rt_accel_build(C.byref(s), C.byref(v))
     if rc != RT_OK:
         raise RuntimeError(f"rt_accel_build failed ({rc})")
     try:

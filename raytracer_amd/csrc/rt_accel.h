@@ -46,6 +46,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <thread>
 #include <vector>
 
@@ -383,7 +384,12 @@ inline bool box_inside(const RtNode& c, const RtNode& p) {
   return true;
 }
 
-inline Result build(const RtScene* s) {
+// `device_tree`: builds the binary tree of the subtree under a reference node into a TreeBuilder, as
+// TreeBuilder::finish leaves it, or returns false (rt_accel_device.h: the same tree, built on the GPU); subtrees of fewer
+// than kDeviceMinTris triangles, and those it declines, are built here on host threads.
+using DeviceTree = std::function<bool(const RtScene*, uint32_t, TreeBuilder&)>;
+constexpr uint32_t kDeviceMinTris = 16384;
+inline Result build(const RtScene* s, const DeviceTree& device_tree = nullptr) {
   Result r;
   const uint32_t nn = s->n_nodes;
   // RT_TIMING=1 in the environment: stage times on stderr
@@ -539,13 +545,20 @@ inline Result build(const RtScene* s) {
       TreeBuilder tb;
       tb.geom = s->tri_geom;
       tb.shapes_ = s->shapes;
-      while (((size_t)todo.size() << tb.par_levels) < 16) tb.par_levels++;  // about 16 threads in all
-      bool ok = true;
-      for (uint32_t i = R; ok && i < s->nodes[R].skip; i++) {
-        const RtNode& n = s->nodes[i];
-        for (uint32_t k = 0; ok && k < n.n_shapes; k++) ok = tb.add(n.first_tri + k, n.first_shape + k, i);
+      if (device_tree && inst[j].n_items >= kDeviceMinTris && device_tree(s, R, tb)) {
+        outs[j].ok = true;
+      } else {
+        tb = TreeBuilder();
+        tb.geom = s->tri_geom;
+        tb.shapes_ = s->shapes;
+        while (((size_t)todo.size() << tb.par_levels) < 16) tb.par_levels++;  // about 16 threads in all
+        bool ok = true;
+        for (uint32_t i = R; ok && i < s->nodes[R].skip; i++) {
+          const RtNode& n = s->nodes[i];
+          for (uint32_t k = 0; ok && k < n.n_shapes; k++) ok = tb.add(n.first_tri + k, n.first_shape + k, i);
+        }
+        outs[j].ok = ok && tb.finish();
       }
-      outs[j].ok = ok && tb.finish();
       if (outs[j].ok) {
         outs[j].nodes = std::move(tb.nodes);
         outs[j].tris = std::move(tb.tris);

@@ -35,7 +35,9 @@ struct Lim {
 #ifndef RT_XS_CAP
 #define RT_XS_CAP 96         // per-ray entries for the n1/n2 container walk
 #endif
+#ifndef RT_AUX_STACK
 #define RT_AUX_STACK 32      // per-lane auxiliary-BVH stack entries, kept in LDS (rt_accel.h: 3 per level of the 4-wide tree, kMaxDepth / 2 levels, + 2)
+#endif
 #ifndef RT_BLOCK
 #define RT_BLOCK 256         // threads per block of every kernel that traces (LDS stack stride): 256 or 64
 #endif

@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "rt_accel.h"
+#include "rt_accel_device.h"
 #include "rt_device.h"
 
 using namespace rtd;
@@ -910,7 +911,16 @@ int rt_scene_create(RtContext* ctx, const RtScene* s, RtDeviceScene** out) {
   // the library's own acceleration data -- auxiliary BVHs under triangle-heavy groups and the cull records of transformed
   // groups (rt_accel.h) -- depend on the caller's arrays only: they are built on threads of their own while this one
   // prepares and uploads the shapes (0.22 + 0.04 s of a 0.34 s call for dragons.yaml)
-  std::future<rtaccel::Result> acc_job = std::async(std::launch::async, [s] { return rtaccel::build(s); });
+  // (the big trees themselves on the device, rt_accel_device.h, on a stream of the builder's own; RT_HOST_ACCEL_BUILD=1
+  // in the environment keeps them on host threads: the two give the same trees)
+  const int dev_for_trees = ctx->device;
+  const bool host_trees = std::getenv("RT_HOST_ACCEL_BUILD") != nullptr;
+  std::future<rtaccel::Result> acc_job = std::async(std::launch::async, [s, dev_for_trees, host_trees] {
+    if (host_trees) return rtaccel::build(s);
+    return rtaccel::build(s, [dev_for_trees](const RtScene* sc, uint32_t root, rtaccel::TreeBuilder& tb) {
+      return rtaccel_dev::build_tree(dev_for_trees, sc, root, tb);
+    });
+  });
   std::future<rtaccel::NodeCull> cull_job = std::async(std::launch::async, [s] { return rtaccel::build_node_cull(s); });
   {
     // device copy of the shapes: bounded analytic shapes get a cull record (rt_accel.h), its index in `prim`
@@ -1076,9 +1086,30 @@ void rt_scene_destroy(RtContext* ctx, RtDeviceScene* ds) {
   delete ds;
 }
 
+static int accel_view(rtaccel::Result* r, RtAccelView* out);
 int rt_accel_build(const RtScene* s, RtAccelView* out) {
   if (!s || !out) return RT_E_ABI;
-  rtaccel::Result* r = new rtaccel::Result(rtaccel::build(s));
+  return accel_view(new rtaccel::Result(rtaccel::build(s)), out);
+}
+int rt_accel_build_device(RtContext* ctx, const RtScene* s, RtAccelView* out) {
+  if (!ctx || !s || !out) return RT_E_ABI;
+  bool needs_big = false;
+  int rc = validate_scene(ctx, s, &needs_big);
+  if (rc != RT_OK) return rc;
+  const int dev = ctx->device;
+  uint32_t declined = 0;
+  rtaccel::Result* r = new rtaccel::Result(rtaccel::build(s, [dev, &declined](const RtScene* sc, uint32_t root, rtaccel::TreeBuilder& tb) {
+    const bool ok = rtaccel_dev::build_tree(dev, sc, root, tb);
+    if (!ok) declined++;
+    return ok;
+  }));
+  (void)hipSetDevice(ctx->device);
+  rc = accel_view(r, out);
+  // (a tree the device builder declined was built on host threads: the view is complete either way)
+  if (declined) ctx->error = std::to_string(declined) + " tree(s) built on the host";
+  return rc;
+}
+static int accel_view(rtaccel::Result* r, RtAccelView* out) {
   out->n_nodes = r->nodes.size();
   out->n_tris = r->tris.size();
   out->n_roots = r->root_of.size();

@@ -340,6 +340,7 @@ extern "C" {
     pub fn rt_scene_create(ctx: *mut RtContext, scene: *const RtScene, out: *mut *mut RtDeviceScene) -> c_int;
     pub fn rt_scene_destroy(ctx: *mut RtContext, scene: *mut RtDeviceScene);
     pub fn rt_accel_build(scene: *const RtScene, out: *mut RtAccelView) -> c_int;
+    pub fn rt_accel_build_device(ctx: *mut RtContext, scene: *const RtScene, out: *mut RtAccelView) -> c_int;
     pub fn rt_accel_free(view: *mut RtAccelView);
     pub fn rt_part_rows(cam: *const RtCamera, opts: *const RtRenderOptions) -> u32;
     pub fn rt_render(

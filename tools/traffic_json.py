@@ -8,13 +8,14 @@ import sys
 text = open(sys.argv[1]).read()
 vals = {}
 for line in text.splitlines():
-    m = re.match(r"(.*k_render_jobs<false, false, false>.*?)\s+(FETCH_SIZE|WRITE_SIZE)\s+(\d+)\s+([\d.]+)", line)
-    if m:
-        vals[m.group(2)] = (float(m.group(4)), int(m.group(3)))
+    # the timed frames go through one instantiation that does not count work (first template argument false)
+    m = re.match(r"(k_render_(?:jobs|direct)<false, [^>]*>)\s+(FETCH_SIZE|WRITE_SIZE)\s+(\d+)\s+([\d.]+)", line)
+    if m and int(m.group(3)) > vals.get(m.group(2), (0, 0, ""))[1]:
+        vals[m.group(2)] = (float(m.group(4)), int(m.group(3)), m.group(1))
 bench = [json.loads(ln) for ln in text.splitlines() if ln.startswith('{"metric"')]
 wl = bench[-1]["config"]["workload"].split(" recursion_limit")[0] if bench else "?"
 print(json.dumps({
-    "workload": wl, "parts": 1, "kernel": "k_render_jobs<false, false, false>",
+    "workload": wl, "parts": 1, "kernel": vals.get("FETCH_SIZE", (0, 0, "?"))[2],
     "fetch_kb": vals.get("FETCH_SIZE", (None,))[0], "write_kb": vals.get("WRITE_SIZE", (None,))[0],
     "source": f"{sys.argv[2]} (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, per dispatch average of "
               f"{vals.get('FETCH_SIZE', (0, 0))[1]})",
