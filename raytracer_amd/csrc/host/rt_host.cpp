@@ -806,13 +806,18 @@ struct RtbWorld {
     // (divide_template, the same rule on the same boxes), copied for every instance
     if (groups[g].fresh_mesh && groups[g].parent >= 0 && groups[g].shapes.empty() && groups[g].children.empty()) {
       const std::pair<int, int> key(groups[g].mesh, threshold);
+      const bool timing = std::getenv("RT_TIMING") != nullptr;
+      auto t0 = std::chrono::steady_clock::now();
       auto it = div_cache.find(key);
       if (it == div_cache.end()) {
         DivTemplate t;
         divide_template(*meshes[groups[g].mesh], groups[g].mtris, threshold, t, 4);
         it = div_cache.emplace(key, std::move(t)).first;
+        if (timing) std::fprintf(stderr, "divide: template of %zu groups %.1f ms\n", it->second.nodes.size(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+        t0 = std::chrono::steady_clock::now();
       }
       instantiate(g, it->second, 0);
+      if (timing) std::fprintf(stderr, "divide: instance %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
       return;
     }
     if (threshold <= group_len(g)) {
