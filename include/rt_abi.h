@@ -214,6 +214,9 @@ typedef struct {
 #define RT_RENDER_NO_PRUNE 0x1u   /* visit every node the reference visits (no distance pruning) */
 #define RT_RENDER_COUNT_WORK 0x2u /* instrumented kernel: also fill the work counters of RtStats (slower) */
 #define RT_RENDER_WORK_MAP 0x8u   /* with COUNT_WORK: RtAux.hit_t receives each pixel's traversal work (box + shape tests) */
+#define RT_RENDER_SHORT_STACK 0x10u /* diagnostics: the traversal stack of the auxiliary trees holds 5 entries; a ray whose
+                                     * traversal needs more takes the reference's walk through that subtree, which is
+                                     * what happens (with 20 entries) in the kernel for worlds of groups only. Same image. */
 #define RT_RENDER_NO_ACCEL 0x4u   /* test every own triangle of a group linearly, as the reference does
                                      (groups.rs:118-120), instead of through the library's auxiliary BVHs */
 

@@ -14,7 +14,7 @@ RT_NODE_ALL_TRIS, RT_NODE_PRUNABLE = 1, 2
 RT_CSG_LEFT_IS_SHAPE, RT_CSG_RIGHT_IS_SHAPE = 1, 2
 RT_JITTER_CONST, RT_JITTER_COUNTER = 0, 1
 RT_DITHER_NONE, RT_DITHER_BAYER2, RT_DITHER_BAYER4, RT_DITHER_BAYER8, RT_DITHER_BAYER16, RT_DITHER_BAYER_COLOR = range(6)
-RT_RENDER_NO_PRUNE, RT_RENDER_COUNT_WORK, RT_RENDER_NO_ACCEL, RT_RENDER_WORK_MAP = 1, 2, 4, 8
+RT_RENDER_NO_PRUNE, RT_RENDER_COUNT_WORK, RT_RENDER_NO_ACCEL, RT_RENDER_WORK_MAP, RT_RENDER_SHORT_STACK = 1, 2, 4, 8, 16
 
 # numpy dtypes of the device records (must match the C structs byte for byte)
 XFORM = np.dtype([("m", "<f4", 12)])

@@ -771,8 +771,16 @@ __device__ inline void csg_eval(const Scene& sc, RtCsgRoot root, const Ray& ray,
 // (groups.rs:118-120); the BVH only skips triangles the test would have rejected, and an accepted
 // triangle is kept only if the reference's own box tests would have let the ray reach it.
 // ---------------------------------------------------------------------------------------
+// ROWS: RT_AUX_STACK, which no traversal can outgrow, or fewer (the kernel for worlds of groups only keeps
+// RT_AUX_ROWS_LEAN so that four of its blocks fit a CU): a traversal that would need more gives up and its ray takes
+// the reference walk through the subtree instead (aux_coop: key 1).
+#ifndef RT_AUX_ROWS_LEAN
+#define RT_AUX_ROWS_LEAN 20
+#endif
+#define RT_AUX_ROWS_TEST 5  // RT_RENDER_SHORT_STACK: so few that the giving up is exercised (tests)
+template <int ROWS>
 __device__ __forceinline__ uint32_t* aux_stack() {
-  __shared__ uint32_t stk[RT_AUX_STACK * RT_BLOCK];
+  __shared__ uint32_t stk[ROWS * RT_BLOCK];
   return stk + threadIdx.x;
 }
 // Conservative slab test against a box widened by `pad`: never reports a miss for a line that comes
@@ -796,10 +804,12 @@ __device__ __forceinline__ bool aux_box(V3 o, V3 inv, float pad, f4n mn, f4n mx,
 // pushes the others onto the lane's stack, farthest first; RT_AUX_NONE when none is hit.
 //   K = |e1||e2||d| / |det| <= kmax for every accepted hit; the cone gives the usually far smaller bound
 //   K <= 1 / (sin(e1,e2) * |cos(d, normal)|): |cos(d, normal)| >= cos(phi + w) for every triangle below, phi = angle(d, axis)
+// rows: how many entries the stack may hold (wave-uniform); `full` is set, and nothing pushed, when they do not suffice
 template <bool COUNT>
 __device__ __forceinline__ uint32_t aux_node4(const Scene& sc, const uint32_t idx, const V3 o, const V3 inv, const V3 dn,
                                               const float kmax, const float padk, const float inv_dm, const bool use_cone,
-                                              const float lo0, const float lim, uint32_t* stk, int& sp, Counters& cn) {
+                                              const float lo0, const float lim, uint32_t* stk, int& sp, Counters& cn,
+                                              const int rows, bool& full) {
   const f4n RT_CONST_AS* N = cst(reinterpret_cast<const f4n*>(sc.aux_nodes)) + 8u * (size_t)idx;
   const f4n q0 = N[0], q1 = N[1], q2 = N[2], q3 = N[3], q4 = N[4], q5 = N[5], q6 = N[6], q7 = N[7];
   RT_UTIL(0);
@@ -846,12 +856,12 @@ __device__ __forceinline__ uint32_t aux_node4(const Scene& sc, const uint32_t id
   RT_CSWAP(t1, r1, t2, r2)
 #undef RT_CSWAP
   const int n_push = (r1 != RT_AUX_NONE) + (r2 != RT_AUX_NONE) + (r3 != RT_AUX_NONE);
-  if (sp + n_push <= RT_AUX_STACK) {
+  if (sp + n_push <= rows) {
     if (r3 != RT_AUX_NONE) stk[(sp++) * RT_BLOCK] = r3;
     if (r2 != RT_AUX_NONE) stk[(sp++) * RT_BLOCK] = r2;
     if (r1 != RT_AUX_NONE) stk[(sp++) * RT_BLOCK] = r1;
   } else {
-    cn.overflow++;
+    full = true;
   }
   return r0;
 }
@@ -901,7 +911,7 @@ __device__ inline bool aux_intersect(const Scene& sc, uint32_t root_node, uint32
   // already small against the tree's triangles
   const bool use_cone = padk * kmax > RT_CONE_MIN_PAD * h1.x;
   V3 inv = v3(__builtin_amdgcn_rcpf(cur.d.x), __builtin_amdgcn_rcpf(cur.d.y), __builtin_amdgcn_rcpf(cur.d.z));
-  uint32_t* stk = aux_stack();
+  uint32_t* stk = aux_stack<RT_AUX_STACK>();
   int sp = 0;
   // entry record: {centre, radius}{lmax, amax, top node, first shape of this instance}; the tree may be shared
   // between instances, so its leaves hold shape and group indices relative to the instance
@@ -913,7 +923,10 @@ __device__ inline bool aux_intersect(const Scene& sc, uint32_t root_node, uint32
   while (true) {
     uint32_t cnt = ref & 15u, idx = ref >> 4;  // reference = index << 4 | leaf triangle count (0: inner node)
     if (cnt == 0u) {
-      const uint32_t next = aux_node4<COUNT>(sc, idx, cur.o, inv, dn, kmax, padk, inv_dm, use_cone, lo0, sink.limit(), stk, sp, cn);
+      bool full = false;
+      const uint32_t next = aux_node4<COUNT>(sc, idx, cur.o, inv, dn, kmax, padk, inv_dm, use_cone, lo0, sink.limit(), stk, sp, cn,
+                                             RT_AUX_STACK, full);
+      if (full) cn.overflow++;  // (RT_AUX_STACK rows hold every traversal of a tree of rt_accel.h's depth)
       if (next != RT_AUX_NONE) {
         ref = next;
         continue;
@@ -1004,18 +1017,26 @@ struct CoopTask {
 template <bool COUNT>
 __device__ __forceinline__ void coop_step(const Scene& sc, Counters& cn, const CoopTask& K, const uint32_t shape_base,
                                           const uint32_t root_node, unsigned long long* keys, uint32_t* stk, uint32_t& ref,
-                                          int& sp, const int bot, bool& work) {
+                                          int& sp, const int bot, bool& work, const int rows) {
   const unsigned long long kcur = __hip_atomic_load(&keys[K.Towner], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   // nothing at or beyond lim can matter: the owner's best so far, capped by its bound (shadow: the light);
-  // key 0 = a shadow search that has its occluder
-  const float lim = kcur == 0ull ? -__builtin_inff() : __builtin_fminf(__uint_as_float((uint32_t)(kcur >> 32)), K.Tbound);
+  // key 0 = a shadow search that has its occluder, key 1 = the search was given up (a stack ran full, see aux_coop)
+  const float lim = kcur <= 1ull ? -__builtin_inff() : __builtin_fminf(__uint_as_float((uint32_t)(kcur >> 32)), K.Tbound);
   uint32_t next = RT_AUX_NONE;
   const uint32_t cnt = ref & 15u, idx = ref >> 4;
-  if (kcur == 0ull) {
+  if (kcur <= 1ull) {
     sp = bot;  // drop what is left
   } else if (cnt == 0u) {
     // closest / shadow searches never want t <= 0
-    next = aux_node4<COUNT>(sc, idx, K.T.o, K.inv, K.dn, K.Tkmax, K.Tpadk, K.inv_dm, K.use_cone, 0.f, lim, stk, sp, cn);
+    bool full = false;
+    next = aux_node4<COUNT>(sc, idx, K.T.o, K.inv, K.dn, K.Tkmax, K.Tpadk, K.inv_dm, K.use_cone, 0.f, lim, stk, sp, cn, rows, full);
+    if (full) {
+      // children that found no room are children nobody visits: the owner's search is void (smaller than every key of a
+      // hit, so it stays; only an occluder already found, key 0, stands: that answer does not need the rest)
+      __hip_atomic_fetch_min(&keys[K.Towner], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      next = RT_AUX_NONE;
+      sp = bot;
+    }
   } else {
     if (COUNT) cn.tri_tests += cnt;
     RT_UTIL(1);
@@ -1104,7 +1125,7 @@ __device__ __forceinline__ bool coop_steal(const unsigned long long busy, const 
 
 // want: this lane's ray reached the subtree root (wave-uniform root_node / aux_root).  handled (for lanes that want):
 // false = this ray must take the reference walk through the subtree.  Every lane of the wave must call.
-template <bool COUNT, class Sink>
+template <bool COUNT, int ROWS, class Sink>
 __device__ inline void aux_coop(const Scene& sc, const uint32_t root_node, const uint32_t aux_root, const Ray& cur, Sink& sink,
                                 Counters& cn, const bool want, bool& handled) {
   const f4n RT_CONST_AS* A = cst(reinterpret_cast<const f4n*>(sc.aux_nodes)) + 8u * (size_t)aux_root;
@@ -1129,13 +1150,14 @@ __device__ inline void aux_coop(const Scene& sc, const uint32_t root_node, const
   unsigned long long* keys = aux_keys();
   const unsigned long long key0 = hit_key(sink.t, sink.shape);
   if (work) __hip_atomic_store(&keys[K.Towner], key0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  uint32_t* stk = aux_stack();
+  uint32_t* stk = aux_stack<ROWS>();
+  const int rows = (ROWS > RT_AUX_ROWS_TEST && (sc.flags & RT_RENDER_SHORT_STACK)) ? RT_AUX_ROWS_TEST : ROWS;
   int sp = 0, bot = 0;  // deferred subtrees of this lane: rows [bot, sp) of its column
   uint32_t ref = __float_as_uint(h1.z) << 4;
   uint32_t iter = 0;
   while (true) {
     // one kind of step per iteration (coop_steps_now)
-    if (coop_steps_now(work, ref)) coop_step<COUNT>(sc, cn, K, shape_base, root_node, keys, stk, ref, sp, bot, work);
+    if (coop_steps_now(work, ref)) coop_step<COUNT>(sc, cn, K, shape_base, root_node, keys, stk, ref, sp, bot, work, rows);
     const unsigned long long busy = __builtin_amdgcn_ballot_w64(work);
     if (busy == 0ull) break;
     // ---- hand deferred subtrees to lanes without work ----
@@ -1148,7 +1170,9 @@ __device__ inline void aux_coop(const Scene& sc, const uint32_t root_node, const
   // ---- the owner takes its result ----
   if (handled) {
     const unsigned long long k = __hip_atomic_load(&keys[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    if (sink.mode == SINK_ANY_SHADOW) {
+    if (k == 1ull) {
+      handled = false;  // some lane's stack ran full on this ray: nothing is taken from the tree, the reference walk decides
+    } else if (sink.mode == SINK_ANY_SHADOW) {
       if (k == 0ull) {
         sink.lim = -__builtin_inff();
         sink.bound = -__builtin_inff();
@@ -1285,7 +1309,7 @@ __device__ RT_WI_INLINE void world_intersect(const Scene& sc, const Ray& ray, Si
         }
         if (wave_any(want)) {  // closest / shadow searches: the whole wave traverses, idle lanes help (aux_coop)
           bool handled = false;
-          aux_coop<COUNT>(sc, i, w3.w, cur, sink, cn, want, handled);
+          aux_coop<COUNT, FEAT == RT_F_GROUPS ? RT_AUX_ROWS_LEAN : RT_AUX_STACK>(sc, i, w3.w, cur, sink, cn, want, handled);
           if (handled) descend = false;
         }
         RT_TACC(t_aux, ta);

@@ -268,6 +268,7 @@ pub struct RtRenderOptions {
 pub const RT_RENDER_NO_PRUNE: u32 = 0x1;
 pub const RT_RENDER_COUNT_WORK: u32 = 0x2;
 pub const RT_RENDER_WORK_MAP: u32 = 0x8;
+pub const RT_RENDER_SHORT_STACK: u32 = 0x10;
 pub const RT_RENDER_NO_ACCEL: u32 = 0x4;
 
 #[repr(C)]

@@ -244,6 +244,27 @@ def test_single_feature_kernels_change_nothing(name, obj_files, monkeypatch):
     assert (ls.primary, ls.shadow, ls.reflect, ls.refract, ls.overflow) == (fs.primary, fs.shadow, fs.reflect, fs.refract, 0)
 
 
+def test_a_traversal_stack_that_runs_full_changes_nothing(monkeypatch):
+    """The kernel for worlds of groups only keeps 20 of the 32 rows of the auxiliary traversal's stack (four blocks a CU);
+    a ray whose traversal needs more is given up there and takes the reference's walk through the subtree (rt_device.h
+    aux_coop, key 1).  RT_RENDER_SHORT_STACK leaves 5 rows, which many rays of this frame outgrow: same bytes and ids,
+    through the lean kernel and the complete one, and the reference walk shows in the work counters."""
+    from raytracer_amd import synth
+    scene = Scene.from_file(scene_path("dragons"), meshes={"dragon.obj": synth.synth_dragon(120, 120)})
+    raw = Raw(scene, (480, 270))
+    full, ids, st = raw.render()
+    short, sids, ss = raw.render(flags=abi.RT_RENDER_SHORT_STACK)
+    assert np.array_equal(full.view(np.uint32), short.view(np.uint32)) and np.array_equal(ids, sids)
+    assert (ss.primary, ss.shadow, ss.reflect, ss.refract, ss.overflow) == (st.primary, st.shadow, st.reflect, st.refract, 0)
+    _, _, cw = raw.render(flags=abi.RT_RENDER_COUNT_WORK)
+    _, _, cs = raw.render(flags=abi.RT_RENDER_COUNT_WORK | abi.RT_RENDER_SHORT_STACK)
+    # nearly every traversal gives up after a few steps and the groups' own triangles are tested one by one instead
+    assert 4 * cs.aux_tests < cw.aux_tests and 2 * cs.tri_tests > 3 * cw.tri_tests and cs.overflow == 0
+    monkeypatch.setenv("RT_NO_LEAN", "1")
+    cshort, cids, _ = raw.render(flags=abi.RT_RENDER_SHORT_STACK)
+    assert np.array_equal(full.view(np.uint32), cshort.view(np.uint32)) and np.array_equal(ids, cids)
+
+
 @pytest.mark.parametrize("size", [(1, 1), (7, 3), (65, 9), (130, 67)])
 def test_ragged_frames_match_oracle(size):
     """Frames that are not whole 8x8 tiles (the work queue hands out items outside the image) and ragged parts:
