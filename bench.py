@@ -256,14 +256,12 @@ def main():
     hbm_gbs = traffic / ksec / 1e9 if traffic else None
     hbm_frac = hbm_gbs / HBM_PEAK_GBS if traffic else 0.0
     valu_frac = valu_tflops / VALU_PEAK_NO_FMA
-    # the kernel is bound by instruction issue and memory latency (lane utilisation, dependent fetches), far below both
-    # roofs; the line names the nearer one
-    if hbm_frac >= valu_frac:
-        roofline = {"bound": "hbm", "achieved": round(hbm_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(hbm_frac, 5)}
-    else:
-        roofline = {"bound": "valu", "achieved": round(valu_tflops, 3), "peak": VALU_PEAK_NO_FMA, "unit": "TFLOP/s",
-                    "frac": round(valu_frac, 5)}
+    # The kernel is bound by instruction issue and memory latency (lane utilisation, dependent fetches), far below both
+    # roofs.  The fraction reported is the one of USEFUL work: algorithmic flops against the VALU roof.  The measured HBM
+    # traffic is given beside it (`hbm`), not as the fraction: in the four-wave kernel two thirds of it are spilled
+    # registers going to scratch and back, bytes the algorithm does not ask for.
+    roofline = {"bound": "valu", "achieved": round(valu_tflops, 3), "peak": VALU_PEAK_NO_FMA, "unit": "TFLOP/s",
+                "frac": round(valu_frac, 5)}
     roofline.update({
         "traffic": traffic, "traffic_source": traffic_src,
         "kernel": "k_render_jobs", "kernel_ms": round(kernel_ms, 3),

@@ -63,6 +63,7 @@ struct Lim {
 #define RT_F_AREA 8u     // lights other than point lights
 #define RT_F_GROUPS 16u  // the reference walk over groups and the auxiliary trees below them
 #define RT_F_ALL 31u
+#define RT_F_WAVES4 32u  // not a feature of the scene: with RT_F_GROUPS alone, the instantiation at four waves per SIMD (rt_hip.hip)
 #define RT_SCENE_RI_ALL_ONE 0x2u   // Scene::props: every material has refractive_index == 1 (n1 = n2 = 1 always)
 
 namespace rtd {
@@ -1309,7 +1310,7 @@ __device__ RT_WI_INLINE void world_intersect(const Scene& sc, const Ray& ray, Si
         }
         if (wave_any(want)) {  // closest / shadow searches: the whole wave traverses, idle lanes help (aux_coop)
           bool handled = false;
-          aux_coop<COUNT, FEAT == RT_F_GROUPS ? RT_AUX_ROWS_LEAN : RT_AUX_STACK>(sc, i, w3.w, cur, sink, cn, want, handled);
+          aux_coop<COUNT, FEAT == (RT_F_GROUPS | RT_F_WAVES4) ? RT_AUX_ROWS_LEAN : RT_AUX_STACK>(sc, i, w3.w, cur, sink, cn, want, handled);
           if (handled) descend = false;
         }
         RT_TACC(t_aux, ta);

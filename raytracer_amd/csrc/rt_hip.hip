@@ -203,13 +203,18 @@ struct PixelSource {
 #ifndef RT_FLAT_WAVES_PER_EU
 #define RT_FLAT_WAVES_PER_EU 4  // 103-116 VGPRs without the walk: four waves per SIMD without a spill
 #endif
-// The kernel for worlds of groups and nothing else (dragons.yaml): four waves per SIMD too, at 128 VGPRs with ~58 of them
-// spilled and RT_AUX_ROWS_LEAN rows of traversal stack in LDS so that four blocks fit a CU (rt_device.h aux_stack): 3 %
-// faster than three waves without a spill (dragons 4K 2.26 -> 2.19 ms)
+// The kernel for worlds of groups and nothing else (dragons.yaml) exists twice: at three waves per SIMD without a
+// spill, and (RT_F_WAVES4) at four, 128 VGPRs with ~51 of them spilled and RT_AUX_ROWS_LEAN rows of traversal stack in LDS
+// so that four blocks fit a CU (rt_device.h aux_stack).  Four waves hide more of the fetches and win where there is work
+// for them (dragons 4K 2.27 -> 2.12 ms, 1080p 0.85 -> 0.83 ms); a launch that is mostly its own tail -- an eighth of the
+// frame -- is faster on the waves that do not spill (0.57 against 0.60 ms): jobs_kernel picks by the number of pixels.
 #ifndef RT_LEAN_WAVES_PER_EU
 #define RT_LEAN_WAVES_PER_EU 4
 #endif
-#define RT_JOBS_WAVES ((FEAT & RT_F_GROUPS) ? (FEAT == RT_F_GROUPS ? RT_LEAN_WAVES_PER_EU : RT_WAVES_PER_EU) : RT_FLAT_WAVES_PER_EU)
+#ifndef RT_LEAN_MIN_PIXELS
+#define RT_LEAN_MIN_PIXELS 1500000ull
+#endif
+#define RT_JOBS_WAVES ((FEAT & RT_F_GROUPS) ? ((FEAT & RT_F_WAVES4) ? RT_LEAN_WAVES_PER_EU : RT_WAVES_PER_EU) : RT_FLAT_WAVES_PER_EU)
 template <bool COUNT, bool CULL, bool SIDE = false, uint32_t FEAT = RT_F_ALL>
 __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_JOBS_WAVES, RT_JOBS_WAVES)))
 void k_render_jobs(Scene sc, RtCamera cam, RenderParams rp, PartInfo part, PixelOut o, unsigned long long* counters) {
@@ -811,13 +816,15 @@ struct JobsPick {
   uint32_t blocks_per_cu;  // resident 256-thread blocks per CU = the kernel's waves per SIMD
 };
 template <bool CULL>
-static JobsPick jobs_kernel(uint32_t need) {
+static JobsPick jobs_kernel(uint32_t need, uint64_t pixels) {
   const bool complete = std::getenv("RT_NO_LEAN") != nullptr;
   if (complete) return {k_render_jobs<false, CULL>, RT_BLOCKS_PER_CU};
   if (!(need & ~RT_F_PATTERN)) return {k_render_jobs<false, CULL, false, RT_F_PATTERN>, RT_FLAT_WAVES_PER_EU};
   if (!(need & ~RT_F_COLLECT)) return {k_render_jobs<false, CULL, false, RT_F_COLLECT>, RT_FLAT_WAVES_PER_EU};
   if (!(need & ~RT_F_CSG)) return {k_render_jobs<false, CULL, false, RT_F_CSG>, RT_FLAT_WAVES_PER_EU};
-  if (!(need & ~RT_F_GROUPS)) return {k_render_jobs<false, CULL, false, RT_F_GROUPS>, RT_LEAN_WAVES_PER_EU};
+  if (!(need & ~RT_F_GROUPS) && pixels >= RT_LEAN_MIN_PIXELS)
+    return {k_render_jobs<false, CULL, false, RT_F_GROUPS | RT_F_WAVES4>, RT_LEAN_WAVES_PER_EU};
+  if (!(need & ~RT_F_GROUPS)) return {k_render_jobs<false, CULL, false, RT_F_GROUPS>, RT_BLOCKS_PER_CU};
   return {k_render_jobs<false, CULL>, RT_BLOCKS_PER_CU};
 }
 
@@ -1170,7 +1177,8 @@ static int launch_part(RtContext* ctx, const Scene& sc, const RtCamera* cam, con
     if (cam->hsize > 0xFFFFu || part.rows > 0xFFFFu) return fail(ctx, RT_E_ABI, "image too large (65535 pixels a side)");
     const bool cull = (sc.props & RT_SCENE_SHAPE_CULL) != 0;  // the scene has cull records (rt_scene_create)
     JobsPick pick = count ? (cull ? JobsPick{k_render_jobs<true, true>, RT_BLOCKS_PER_CU} : JobsPick{k_render_jobs<true, false>, RT_BLOCKS_PER_CU})
-                          : (cull ? jobs_kernel<true>(scene_features(sc)) : jobs_kernel<false>(scene_features(sc)));
+                          : (cull ? jobs_kernel<true>(scene_features(sc), (uint64_t)cam->hsize * part.rows)
+                                  : jobs_kernel<false>(scene_features(sc), (uint64_t)cam->hsize * part.rows));
     // a context with side lists: the one instantiation that keeps the n1/n2 lists there (it counts work and tests cull
     // records whether asked to or not: it is the slow path, and one kernel instead of four keeps the build short)
     if (sc.side_cap) pick = JobsPick{k_render_jobs<true, true, true>, RT_BLOCKS_PER_CU};
