@@ -582,7 +582,10 @@ inline bool build_tree(int device, const RtScene* s, uint32_t R, rtaccel::TreeBu
   if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return false;
   struct StreamGuard {
     hipStream_t s;
-    ~StreamGuard() { (void)hipStreamDestroy(s); }
+    ~StreamGuard() {  // (every way out: nothing of this call is in flight once its host vectors go)
+      (void)hipStreamSynchronize(s);
+      (void)hipStreamDestroy(s);
+    }
   } guard{st};
   // the triangles the subtree uses are a few runs of tri_geom: upload the span that holds them
   uint32_t t_lo = 0xFFFFFFFFu, t_hi = 0;
@@ -676,6 +679,7 @@ inline bool build_tree(int device, const RtScene* s, uint32_t R, rtaccel::TreeBu
     while (!stack.empty()) {
       const uint32_t q = stack.back();
       stack.pop_back();
+      if (q == 0 || q >= n_nodes || new_of[q] != 0 || next >= n_nodes) return false;  // not a tree: never seen, but never trusted
       new_of[q] = next++;
       if (bfs[q].rcount == 0) stack.push_back(bfs[q].right);
       if (bfs[q].lcount == 0) stack.push_back(bfs[q].left);
