@@ -244,6 +244,26 @@ def test_single_feature_kernels_change_nothing(name, obj_files, monkeypatch):
     assert (ls.primary, ls.shadow, ls.reflect, ls.refract, ls.overflow) == (fs.primary, fs.shadow, fs.reflect, fs.refract, 0)
 
 
+def test_group_less_mixture_kernel_changes_nothing(tmp_path, monkeypatch):
+    """A world without groups that needs several features at once (cover.yaml's glass with a checker pattern on its
+    white material: the n1/n2 lists and patterns) renders through the instantiation with everything but the group walk,
+    at four waves per SIMD: the same bytes as through the complete kernel."""
+    text = open(scene_path("cover")).read()
+    plain = "- define: white-material\n  material:\n    color: [ 1, 1, 1 ]"
+    assert plain in text
+    text = text.replace(plain, "- define: white-material\n  material:\n    pattern:\n      kind: checker\n      colors:\n"
+                               "        - [1, 1, 1]\n        - [0.6, 0.6, 0.6]\n    color: [ 1, 1, 1 ]", 1)
+    path = tmp_path / "mix.yaml"
+    path.write_text(text)
+    raw = Raw(Scene.from_file(str(path)), (1925, 1083))
+    lean, lids, ls = raw.render()
+    monkeypatch.setenv("RT_NO_LEAN", "1")
+    full, fids, fs = raw.render()
+    assert np.array_equal(lean.view(np.uint32), full.view(np.uint32)) and np.array_equal(lids, fids)
+    assert (ls.primary, ls.shadow, ls.reflect, ls.refract, ls.overflow) == (fs.primary, fs.shadow, fs.reflect, fs.refract, 0)
+    assert ls.refract > 0 and len(np.unique(lean.reshape(-1, 3), axis=0)) > 1000
+
+
 def test_a_traversal_stack_that_runs_full_changes_nothing(monkeypatch):
     """The kernel for worlds of groups only keeps 20 of the 32 rows of the auxiliary traversal's stack (four blocks a CU);
     a ray whose traversal needs more is given up there and takes the reference's walk through the subtree (rt_device.h
