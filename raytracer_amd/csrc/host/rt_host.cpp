@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <functional>
 #include <limits>
 #include <map>
 #include <memory>
@@ -1482,11 +1483,14 @@ int rth_group_add_mesh(RtbWorld* w, int g, const RtbMaterial* material, const fl
   if (npositions < 0 || nnormals < 0 || ntriangles < 0) return fail(w, "negative mesh size");
   const bool has_n = normals && nidx;
   // the same arrays handed in again (scene.rs:593-599 re-parses the file for every `obj:` use): one HMesh
+  // (hashed and compared in 1 MB pieces on threads: dragons.yaml hands the same 31 MB in six times)
+  const bool timing = std::getenv("RT_TIMING") != nullptr;
+  auto t_prev = std::chrono::steady_clock::now();
   auto fnv = [](uint64_t h, const void* p, size_t n) {
-    const uint64_t* q = static_cast<const uint64_t*>(p);
+    const char* q = static_cast<const char*>(p);
     for (size_t i = 0; i + 8 <= n; i += 8) {
       uint64_t v;
-      std::memcpy(&v, reinterpret_cast<const char*>(q) + i, 8);
+      std::memcpy(&v, q + i, 8);
       h = (h ^ v) * 0x100000001B3ull;
       h ^= h >> 31;
     }
@@ -1494,15 +1498,46 @@ int rth_group_add_mesh(RtbWorld* w, int g, const RtbMaterial* material, const fl
     for (size_t i = n & ~(size_t)7; i < n; i++) h = (h ^ c[i]) * 0x100000001B3ull;
     return h;
   };
+  constexpr size_t kPiece = (size_t)1 << 20;
+  auto on_pieces = [](size_t n_pieces, const std::function<void(size_t)>& f) {
+    const unsigned nt = n_pieces >= 4 ? std::max(1u, std::min(8u, std::thread::hardware_concurrency())) : 1u;
+    if (nt == 1) {
+      for (size_t k = 0; k < n_pieces; k++) f(k);
+      return;
+    }
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < nt; t++)
+      pool.emplace_back([&, t] {
+        for (size_t k = t; k < n_pieces; k += nt) f(k);
+      });
+    for (auto& th : pool) th.join();
+  };
+  auto hash_array = [&](uint64_t h, const void* p, size_t n) {
+    const size_t n_pieces = (n + kPiece - 1) / kPiece;
+    std::vector<uint64_t> part(n_pieces);
+    on_pieces(n_pieces, [&](size_t k) {
+      part[k] = fnv(1469598103934665603ull + k, static_cast<const char*>(p) + k * kPiece, std::min(kPiece, n - k * kPiece));
+    });
+    return fnv(h ^ n, part.data(), part.size() * 8);
+  };
+  auto same_bytes = [&](const void* a, const void* b, size_t n) {
+    const size_t n_pieces = (n + kPiece - 1) / kPiece;
+    std::vector<uint8_t> differ(n_pieces, 0);
+    on_pieces(n_pieces, [&](size_t k) {
+      differ[k] = std::memcmp(static_cast<const char*>(a) + k * kPiece, static_cast<const char*>(b) + k * kPiece,
+                              std::min(kPiece, n - k * kPiece)) != 0;
+    });
+    for (uint8_t d : differ)
+      if (d) return false;
+    return true;
+  };
   uint64_t h = 1469598103934665603ull ^ (uint64_t)ntriangles ^ ((uint64_t)npositions << 32);
-  h = fnv(h, positions, (size_t)npositions * 12);
-  h = fnv(h, vidx, (size_t)ntriangles * 12);
+  h = hash_array(h, positions, (size_t)npositions * 12);
+  h = hash_array(h, vidx, (size_t)ntriangles * 12);
   if (has_n) {
-    h = fnv(h, normals, (size_t)nnormals * 12);
-    h = fnv(h, nidx, (size_t)ntriangles * 12);
+    h = hash_array(h, normals, (size_t)nnormals * 12);
+    h = hash_array(h, nidx, (size_t)ntriangles * 12);
   }
-  const bool timing = std::getenv("RT_TIMING") != nullptr;
-  auto t_prev = std::chrono::steady_clock::now();
   auto stage = [&](const char* what) {
     if (!timing) return;
     auto now = std::chrono::steady_clock::now();
@@ -1515,10 +1550,8 @@ int rth_group_add_mesh(RtbWorld* w, int g, const RtbMaterial* material, const fl
     const HMesh& m = *w->meshes[k];
     if (m.hash == h && m.in_pos.size() == (size_t)npositions * 3 && m.in_vidx.size() == (size_t)ntriangles * 3 &&
         m.in_nrm.size() == (has_n ? (size_t)nnormals * 3 : 0) && m.in_nidx.size() == (has_n ? (size_t)ntriangles * 3 : 0) &&
-        std::memcmp(m.in_pos.data(), positions, m.in_pos.size() * 4) == 0 &&
-        std::memcmp(m.in_vidx.data(), vidx, m.in_vidx.size() * 4) == 0 &&
-        (!has_n || (std::memcmp(m.in_nrm.data(), normals, m.in_nrm.size() * 4) == 0 &&
-                    std::memcmp(m.in_nidx.data(), nidx, m.in_nidx.size() * 4) == 0)))
+        same_bytes(m.in_pos.data(), positions, m.in_pos.size() * 4) && same_bytes(m.in_vidx.data(), vidx, m.in_vidx.size() * 4) &&
+        (!has_n || (same_bytes(m.in_nrm.data(), normals, m.in_nrm.size() * 4) && same_bytes(m.in_nidx.data(), nidx, m.in_nidx.size() * 4))))
       mesh = (int)k;
   }
   if (mesh < 0) {
