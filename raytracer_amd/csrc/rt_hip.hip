@@ -818,7 +818,12 @@ struct JobsPick {
 template <bool CULL>
 static JobsPick jobs_kernel(uint32_t need, uint64_t pixels) {
   const bool complete = std::getenv("RT_NO_LEAN") != nullptr;
-  const bool big = pixels >= RT_LEAN_MIN_PIXELS;
+  // (RT_LEAN_MIN_PIXELS in the environment moves the threshold: 0 sends every frame through the four-wave kernel, for tests)
+  static const uint64_t min_pixels = [] {
+    const char* e = std::getenv("RT_LEAN_MIN_PIXELS");
+    return e ? std::strtoull(e, nullptr, 10) : (uint64_t)RT_LEAN_MIN_PIXELS;
+  }();
+  const bool big = pixels >= min_pixels;
   if (!complete) {
     if (!(need & ~RT_F_PATTERN)) return {k_render_jobs<false, CULL, false, RT_F_PATTERN>, RT_FLAT_WAVES_PER_EU};
     if (!(need & ~RT_F_COLLECT)) return {k_render_jobs<false, CULL, false, RT_F_COLLECT>, RT_FLAT_WAVES_PER_EU};
