@@ -47,6 +47,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <future>
 #include <thread>
 #include <vector>
 
@@ -447,6 +448,25 @@ inline Result build(const RtScene* s, const DeviceTree& device_tree = nullptr) {
     std::sort(fit.begin(), fit.end());
     roots.swap(fit);
   }
+  // The first root's tree is needed whatever the instance detection below finds (it is nobody's copy): with a device
+  // builder it is started now and built on the GPU while this thread hashes and compares.
+  struct Early {
+    bool ok = false;
+    TreeBuilder tb;
+  };
+  std::future<Early> early;
+  if (device_tree && !roots.empty()) {
+    uint64_t n0 = 0;
+    for (uint32_t i = roots[0]; i < s->nodes[roots[0]].skip; i++) n0 += s->nodes[i].n_shapes;
+    if (n0 >= kDeviceMinTris)
+      early = std::async(std::launch::async, [s, &device_tree, R0 = roots[0]] {
+        Early e;
+        e.tb.geom = s->tri_geom;
+        e.tb.shapes_ = s->shapes;
+        e.ok = device_tree(s, R0, e.tb);
+        return e;
+      });
+  }
   // Instancing: subtrees with the same triangles in the same arrangement (the reference re-parses and duplicates an
   // OBJ file for every instance, scene.rs:593-599) share one tree.  Leaf triangles hold the shape index relative to
   // the instance's first shape and the owning group relative to the instance's root; every root gets its own
@@ -486,7 +506,7 @@ inline Result build(const RtScene* s, const DeviceTree& device_tree = nullptr) {
   }
   stage("roots, canonical triangles");
   std::vector<Inst> inst(roots.size());
-  for (size_t j = 0; j < roots.size(); j++) {
+  auto hash_root = [&](size_t j) {
     Inst& I = inst[j];
     I.same_as = j;
     I.shape_base = 0xFFFFFFFFu;
@@ -501,6 +521,16 @@ inline Result build(const RtScene* s, const DeviceTree& device_tree = nullptr) {
       h ^= h >> 29;
     });
     I.hash = h;
+  };
+  {  // (one root per thread: six dragons are 5.2 M items)
+    const unsigned nt_h = roots.size() >= 2 ? std::max(1u, std::min<unsigned>(8u, std::min<unsigned>((unsigned)roots.size(), std::thread::hardware_concurrency()))) : 1u;
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < nt_h; t++)
+      pool.emplace_back([&, t] {
+        for (size_t j = t; j < roots.size(); j += nt_h) hash_root(j);
+      });
+    for (size_t j = 0; j < roots.size(); j += nt_h) hash_root(j);
+    for (auto& th : pool) th.join();
   }
   auto same_items = [&](size_t j1, size_t j2) {  // full comparison behind a hash match
     if (inst[j1].n_items != inst[j2].n_items) return false;
@@ -545,7 +575,12 @@ inline Result build(const RtScene* s, const DeviceTree& device_tree = nullptr) {
       TreeBuilder tb;
       tb.geom = s->tri_geom;
       tb.shapes_ = s->shapes;
-      if (device_tree && inst[j].n_items >= kDeviceMinTris && device_tree(s, R, tb)) {
+      Early e;
+      if (j == 0 && early.valid()) e = early.get();
+      if (e.ok) {
+        tb = std::move(e.tb);
+        outs[j].ok = true;
+      } else if (!(j == 0 && e.tb.geom) && device_tree && inst[j].n_items >= kDeviceMinTris && device_tree(s, R, tb)) {
         outs[j].ok = true;
       } else {
         tb = TreeBuilder();

@@ -14,6 +14,7 @@
 #include <cstring>
 #include <functional>
 #include <future>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -946,51 +947,78 @@ int rt_scene_create(RtContext* ctx, const RtScene* s, RtDeviceScene** out) {
   });
   std::future<rtaccel::NodeCull> cull_job = std::async(std::launch::async, [s] { return rtaccel::build_node_cull(s); });
   {
-    // device copy of the shapes: bounded analytic shapes get a cull record (rt_accel.h), its index in `prim`
-    std::vector<RtShape> shapes(s->shapes, s->shapes + s->n_shapes);
+    // device copy of the shapes: bounded analytic shapes get a cull record (rt_accel.h), its index in `prim`.
+    // 5.2 M records for dragons.yaml: the passes over all of them run in pieces on threads; whatever decides an index
+    // (cull records, duplicate links) is put together in piece order, so the result does not depend on the threads.
+    std::unique_ptr<RtShape[]> shapes_mem(new RtShape[std::max<size_t>(s->n_shapes, 1)]);  // (not zeroed first: every piece fills its own)
+    RtShape* const shapes = shapes_mem.get();
+    const uint32_t n_pieces = s->n_shapes >= (1u << 18) ? std::max(1u, std::min(8u, std::thread::hardware_concurrency())) : 1u;
+    auto in_pieces = [&](const std::function<void(uint32_t, uint32_t, uint32_t)>& f) {
+      std::vector<std::thread> pool;
+      for (uint32_t k = 1; k < n_pieces; k++)
+        pool.emplace_back(f, k, (uint32_t)((uint64_t)s->n_shapes * k / n_pieces), (uint32_t)((uint64_t)s->n_shapes * (k + 1) / n_pieces));
+      f(0, 0, (uint32_t)((uint64_t)s->n_shapes / n_pieces));
+      for (auto& t : pool) t.join();
+    };
     std::vector<float> cull;
     // worth its ~25 operations per test only where a ray meets many shapes in a row: the loose shapes of the world or
     // the own shapes of one group, when there are at least RT_CULL_MIN_SHAPES of them
-    for (uint32_t i = 0; i < s->n_shapes; i++) {
-      float rec[12];
-      const int32_t par = shapes[i].parent;
-      const uint32_t siblings = par >= 0 ? s->nodes[par].n_shapes : s->n_loose_shapes;
-      if (siblings >= RT_CULL_MIN_SHAPES && rtaccel::shape_cull_record(s, shapes[i], rec)) {
-        shapes[i].prim = (uint32_t)(cull.size() / 12);
-        shapes[i].kind_flags |= RT_SHAPE_CULLABLE;
-        cull.insert(cull.end(), rec, rec + 12);
-      }
-    }
-    // Which of several value-identical triangles is reported as hit (rt_device.h reported_shape). A mesh that lists
-    // a triangle twice gives two entries equal in (t, Shape, u, v), and of such neighbours the reference's
-    // Intersections keeps the LATER one (BTreeMap bulk build), whereas ties between different shapes
-    // go to the earlier. Duplicates are the same class under the same transformed ancestor; the device copy of a
-    // triangle holds the last of them in the unused `mn` slot.  Duplicates that sit in DIFFERENT groups are merged
-    // too: exact whenever the ray that hits both also passes both groups' box tests, which holds for every mesh
-    // `divide` builds (equal triangles have equal boxes and take the same side at every split); for hand-placed
-    // duplicates in groups with different boxes a ray within rounding of one box's face may report the other id
-    // (the id only: the shapes are equal, so is the colour).
     {
+      std::vector<std::vector<uint32_t>> candidates(n_pieces);  // cubes and spheres with enough siblings
+      std::vector<uint32_t> piece_max(n_pieces, 0);
+      in_pieces([&](uint32_t piece, uint32_t b, uint32_t e) {
+        for (uint32_t i = b; i < e; i++) {
+          shapes[i] = s->shapes[i];
+          const uint32_t kind = shapes[i].kind_flags & RT_SHAPE_KIND_MASK;
+          if (kind >= RT_TRIANGLE) {
+            memcpy(&shapes[i].mn, &i, sizeof(uint32_t));  // reported_shape: itself, until a later duplicate is found
+          } else if (kind == RT_CUBE || kind == RT_SPHERE) {
+            const int32_t par = shapes[i].parent;
+            const uint32_t siblings = par >= 0 ? s->nodes[par].n_shapes : s->n_loose_shapes;
+            if (siblings >= RT_CULL_MIN_SHAPES) candidates[piece].push_back(i);
+          }
+          if (shapes[i].vclass != RT_VCLASS_NEVER) piece_max[piece] = std::max(piece_max[piece], shapes[i].vclass);
+        }
+      });
+      for (const std::vector<uint32_t>& list : candidates)
+        for (uint32_t i : list) {
+          float rec[12];
+          if (rtaccel::shape_cull_record(s, shapes[i], rec)) {
+            shapes[i].prim = (uint32_t)(cull.size() / 12);
+            shapes[i].kind_flags |= RT_SHAPE_CULLABLE;
+            cull.insert(cull.end(), rec, rec + 12);
+          }
+        }
+      // Which of several value-identical triangles is reported as hit (rt_device.h reported_shape). A mesh that lists
+      // a triangle twice gives two entries equal in (t, Shape, u, v), and of such neighbours the reference's
+      // Intersections keeps the LATER one (BTreeMap bulk build), whereas ties between different shapes
+      // go to the earlier. Duplicates are the same class under the same transformed ancestor; the device copy of a
+      // triangle holds the last of them in the unused `mn` slot.  Duplicates that sit in DIFFERENT groups are merged
+      // too: exact whenever the ray that hits both also passes both groups' box tests, which holds for every mesh
+      // `divide` builds (equal triangles have equal boxes and take the same side at every split); for hand-placed
+      // duplicates in groups with different boxes a ray within rounding of one box's face may report the other id
+      // (the id only: the shapes are equal, so is the colour).
       // only classes that occur more than once can have duplicates: count first (one pass), sort the few that remain
-      std::vector<std::pair<uint64_t, uint32_t>> keyed;
-      std::vector<uint8_t> seen;  // per class: 1 = seen once, 2 = more than once
       uint32_t max_class = 0;
+      for (uint32_t m : piece_max) max_class = std::max(max_class, m);
+      std::vector<uint8_t> seen((size_t)max_class + 1, 0);  // per class: 1 = seen once, 2 = more than once
       for (uint32_t i = 0; i < s->n_shapes; i++)
-        if (shapes[i].vclass != RT_VCLASS_NEVER) max_class = std::max(max_class, shapes[i].vclass);
-      seen.assign((size_t)max_class + 1, 0);
-      for (uint32_t i = 0; i < s->n_shapes; i++)
-        if ((shapes[i].kind_flags & RT_SHAPE_KIND_MASK) >= RT_TRIANGLE) {
-          memcpy(&shapes[i].mn, &i, sizeof(uint32_t));
-          // a triangle that holds a NaN equals no shape, itself included: it is nobody's duplicate
-          if (shapes[i].vclass != RT_VCLASS_NEVER && seen[shapes[i].vclass] < 2) seen[shapes[i].vclass]++;
-        }
-      for (uint32_t i = 0; i < s->n_shapes; i++)
+        // a triangle that holds a NaN equals no shape, itself included: it is nobody's duplicate
         if ((shapes[i].kind_flags & RT_SHAPE_KIND_MASK) >= RT_TRIANGLE && shapes[i].vclass != RT_VCLASS_NEVER &&
-            seen[shapes[i].vclass] == 2) {
-          const int32_t par = shapes[i].parent;
-          const int64_t anchor = par >= 0 ? (int64_t)s->nodes[par].next_xf + 1 : 0;
-          keyed.emplace_back(((uint64_t)shapes[i].vclass << 32) | (uint64_t)anchor, i);
-        }
+            seen[shapes[i].vclass] < 2)
+          seen[shapes[i].vclass]++;
+      std::vector<std::vector<std::pair<uint64_t, uint32_t>>> piece_keyed(n_pieces);
+      in_pieces([&](uint32_t piece, uint32_t b, uint32_t e) {
+        for (uint32_t i = b; i < e; i++)
+          if ((shapes[i].kind_flags & RT_SHAPE_KIND_MASK) >= RT_TRIANGLE && shapes[i].vclass != RT_VCLASS_NEVER &&
+              seen[shapes[i].vclass] == 2) {
+            const int32_t par = shapes[i].parent;
+            const int64_t anchor = par >= 0 ? (int64_t)s->nodes[par].next_xf + 1 : 0;
+            piece_keyed[piece].emplace_back(((uint64_t)shapes[i].vclass << 32) | (uint64_t)anchor, i);
+          }
+      });
+      std::vector<std::pair<uint64_t, uint32_t>> keyed;
+      for (auto& list : piece_keyed) keyed.insert(keyed.end(), list.begin(), list.end());
       std::sort(keyed.begin(), keyed.end());
       for (size_t a = 0; a < keyed.size();) {
         size_t b = a + 1;
@@ -1001,7 +1029,7 @@ int rt_scene_create(RtContext* ctx, const RtScene* s, RtDeviceScene** out) {
     }
     stage("cull records, duplicate links");
     const float* dc = nullptr;
-    UP(d.shapes, shapes.data(), shapes.size())
+    UP(d.shapes, (const RtShape*)shapes, (size_t)s->n_shapes)
     UP(dc, cull.data(), cull.size())
     d.shape_cull = reinterpret_cast<const float4*>(dc);
     if (!cull.empty()) d.props |= RT_SCENE_SHAPE_CULL;
