@@ -299,6 +299,9 @@ struct HGroup {
   std::vector<uint32_t> mtris;
   RtbMaterial mmat{};
   bool fresh_mesh = false;  // exactly what group_add_mesh made: every triangle of the mesh in order, nothing else
+  // mtris is the copy of node `tmpl_node` of divide template `tmpl_id` (-1: not, or changed since): the flattener
+  // finds the triangle run of such a group by this key instead of hashing the index sequence
+  int tmpl_id = -1, tmpl_node = -1;
 };
 // The result of `divide` on a fresh mesh group (groups.rs:284-299), kept so that the next instance of the same mesh
 // with the same threshold is a copy of the tree instead of a second partition of 871 k triangles: the partition
@@ -309,6 +312,7 @@ struct DivNode {
 };
 struct DivTemplate {
   std::vector<DivNode> nodes;  // [0] = the mesh group itself
+  int id = -1;
 };
 struct HCsg {
   int op = 0;
@@ -631,6 +635,7 @@ struct RtbWorld {
     made.insert(made.end(), g2.shapes.begin(), g2.shapes.end());
     g2.shapes.swap(made);
     g2.mtris.clear();
+    g2.tmpl_id = g2.tmpl_node = -1;
     g2.mesh = -1;
     g2.fresh_mesh = false;
   }
@@ -692,6 +697,7 @@ struct RtbWorld {
           keept.push_back(t);
       }
       groups[g].mtris = std::move(keept);
+      groups[g].tmpl_id = groups[g].tmpl_node = -1;
       groups[g].fresh_mesh = false;
     }
     std::vector<int> kids;
@@ -738,6 +744,7 @@ struct RtbWorld {
   }
   void instantiate(int g, const DivTemplate& t, int node) {
     groups[g].mtris = t.nodes[node].mtris;
+    groups[g].tmpl_id = t.id, groups[g].tmpl_node = node;
     groups[g].fresh_mesh = false;
     for (int k : t.nodes[node].children) {
       const int c = new_group();
@@ -813,6 +820,7 @@ struct RtbWorld {
       if (it == div_cache.end()) {
         DivTemplate t;
         divide_template(*meshes[groups[g].mesh], groups[g].mtris, threshold, t, 4);
+        t.id = (int)div_cache.size();
         it = div_cache.emplace(key, std::move(t)).first;
         if (timing) std::fprintf(stderr, "divide: template of %zu groups %.1f ms\n", it->second.nodes.size(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
         t0 = std::chrono::steady_clock::now();
@@ -895,7 +903,15 @@ struct Flattener {
     n->n2[0] = t.n2.x, n->n2[1] = t.n2.y, n->n2[2] = t.n2.z;
     n->n3[0] = t.n3.x, n->n3[1] = t.n3.y, n->n3[2] = t.n3.z;
   }
-  const Run& geometry_run(int mesh, const std::vector<uint32_t>& seq) {
+  std::unordered_map<uint64_t, Run> tmpl_runs;  // (divide template, node) -> its run
+  const Run& geometry_run(int mesh, const std::vector<uint32_t>& seq, int tmpl_id, int tmpl_node) {
+    if (tmpl_id >= 0) {
+      const uint64_t key = ((uint64_t)(uint32_t)tmpl_id << 32) | (uint32_t)tmpl_node;
+      auto it = tmpl_runs.find(key);
+      if (it != tmpl_runs.end()) return it->second;
+      const Run& r = geometry_run(mesh, seq, -1, -1);
+      return tmpl_runs.emplace(key, r).first->second;
+    }
     uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)mesh;
     for (uint32_t t : seq) {
       h = (h ^ t) * 0xFF51AFD7ED558CCDull;
@@ -1147,7 +1163,7 @@ struct Flattener {
     if (!gr.mtris.empty()) {  // the triangles of a mesh group, in bulk (a group holds these or shapes, never both)
       const HMesh& m = *w.meshes[gr.mesh];
       auto T1 = std::chrono::steady_clock::now();
-      const Run& run = geometry_run(gr.mesh, gr.mtris);
+      const Run& run = geometry_run(gr.mesh, gr.mtris, gr.tmpl_id, gr.tmpl_node);
       t_run += std::chrono::duration<double>(std::chrono::steady_clock::now() - T1).count();
       first_tri = run.first_tri;
       uint32_t mat_index, mclass;
