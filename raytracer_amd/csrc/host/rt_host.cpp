@@ -825,6 +825,8 @@ struct RtbWorld {
         if (timing) std::fprintf(stderr, "divide: template of %zu groups %.1f ms\n", it->second.nodes.size(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
         t0 = std::chrono::steady_clock::now();
       }
+      if (groups.capacity() < groups.size() + it->second.nodes.size())  // one growth for the whole copy, with room for the next
+        groups.reserve(std::max(groups.capacity() * 2, groups.size() + 2 * it->second.nodes.size()));
       instantiate(g, it->second, 0);
       if (timing) std::fprintf(stderr, "divide: instance %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
       return;
