@@ -15,9 +15,9 @@
 //              prefix sum of "goes left" over all positions, ranges of the children, the permuted triangles
 // The tree that comes out has the boxes, splits and leaves of TreeBuilder's (tests/test_gpu_accel_device.py compares
 // them one by one); cones agree to rounding (the host sums the normals in double in triangle order).  A node for which
-// no split passes takes the object median, as in TreeBuilder (k_median: ranks by counting in LDS, nodes of up to
-// kMedianMax triangles; a larger one makes the builder give up and the caller builds that tree on the host).  Leaves
-// hold a run of the final permutation, so a leaf's first triangle is its `b`.
+// no split passes takes the object median, as in TreeBuilder (k_median: ranks by counting in LDS, for nodes of up to
+// kMedianMax triangles; k_mcount / k_mupdate: the median key by bisection, for larger ones).  Leaves hold a run of the
+// final permutation, so a leaf's first triangle is its `b`.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -58,8 +58,9 @@ struct Glob {
   uint32_t bad;        // a non-finite triangle: the subtree keeps the reference walk (TreeBuilder::add)
   uint32_t n_nodes;    // binary nodes allocated (0 = header, 1 = top)
   uint32_t n_next;     // nodes of the next level
-  uint32_t give_up;    // a node the device does not split (an object-median split of more than kMedianMax triangles)
-  uint32_t n_median;   // nodes of this level that take the object-median split
+  uint32_t give_up;    // (unused: nothing makes the device give a tree up any more; kept for the layout)
+  uint32_t n_median;   // nodes of this level that take the object-median split, up to kMedianMax triangles (k_median)
+  uint32_t n_large;    // ... and larger ones (k_mcount / k_mupdate)
 };
 struct WNode {  // a node of the level being built
   uint32_t b, e, parent, side;
@@ -72,7 +73,9 @@ struct WNode {  // a node of the level being built
   uint32_t axis_ok, cone_ok;
   double axd[3], al;
   uint32_t kind, axis, split, me, child0;
-  uint32_t pad_;
+  uint32_t large;  // an object-median split of more than kMedianMax triangles: the median key is found by bisection
+  unsigned long long mlo, mhi, mmid;  // ... over [mlo, mhi], mmid the key being counted against
+  uint32_t mcnt, pad_;                // ... triangles of the node with key <= mmid
 };
 struct Bin {
   uint32_t cnt;
@@ -90,6 +93,7 @@ __device__ __forceinline__ void wnode_init(WNode& w, uint32_t b, uint32_t e, uin
   w.bad = 0;
   w.cmin = d2o(1.0);
   w.kind = kLeaf;
+  w.large = 0;
 }
 
 __global__ void k_init(uint32_t n, uint32_t* perm, uint32_t* node_of, WNode* wn, Glob* g) {
@@ -99,7 +103,7 @@ __global__ void k_init(uint32_t n, uint32_t* perm, uint32_t* node_of, WNode* wn,
     wnode_init(wn[0], 0, n, kNoW, 0);
     for (int a = 0; a < 3; a++) g->blo[a] = f2o(INFINITY), g->bhi[a] = f2o(-INFINITY);
     g->lmax = g->amax = f2o(0.f);
-    g->bad = 0, g->n_nodes = 1, g->n_next = 0, g->give_up = 0, g->n_median = 0;
+    g->bad = 0, g->n_nodes = 1, g->n_next = 0, g->give_up = 0, g->n_median = 0, g->n_large = 0;
   }
 }
 
@@ -393,17 +397,19 @@ __global__ void k_split(WNode* wn, uint32_t m, const Bin* bins, rtaccel::Node* n
   }
   if (best_axis < 0) {
     // TreeBuilder: the object median on the axis of largest centroid extent (k_median ranks the triangles)
-    if (n > kMedianMax) {
-      atomicOr(&g->give_up, 1u);
-      return;
-    }
     int axis = 0;
     for (int a = 1; a < 3; a++)
       if (o2f(w.chi[a]) - o2f(w.clo[a]) > o2f(w.chi[axis]) - o2f(w.clo[axis])) axis = a;
     w.kind = kMedian;
     w.axis = (uint32_t)axis;
     w.split = 0;
-    median_list[atomicAdd(&g->n_median, 1u)] = i;
+    if (n > kMedianMax) {
+      w.large = 1;
+      w.mlo = 0ull, w.mhi = ~0ull, w.mmid = ~0ull >> 1, w.mcnt = 0;
+      atomicAdd(&g->n_large, 1u);
+    } else {
+      median_list[atomicAdd(&g->n_median, 1u)] = i;
+    }
   } else {
     w.kind = kSplit;
     w.axis = (uint32_t)best_axis;
@@ -455,9 +461,46 @@ __global__ __launch_bounds__(256) void k_median(const uint32_t* perm, const floa
   }
 }
 
+// The same split for nodes too large for that: the order (centroid on the axis, shape index) as one 64-bit key, and the
+// key of the triangle that n / 2 - 1 others precede found by bisection -- 64 rounds of "how many keys of the node are <=
+// mmid" (k_mcount, all such nodes of the level at once) and "which half of the interval" (k_mupdate).  A triangle goes
+// left when its key is <= that key.  (-0 and +0 compare equal in TreeBuilder's order: c + 0 makes them one key.)
+__device__ __forceinline__ unsigned long long median_key(float c, uint32_t shape) {
+  return ((unsigned long long)((uint32_t)f2o(c + 0.f) ^ 0x80000000u) << 32) | shape;
+}
+__global__ void k_mcount(const uint32_t* perm, const uint32_t* node_of, const float* f, const uint32_t* shape, uint32_t n,
+                         WNode* wn) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t key = p < n ? node_of[p] : kNoW;
+  uint32_t below = 0;
+  if (key != kNoW) {
+    const WNode& w = wn[key];
+    if (w.kind == kMedian && w.large) {
+      const uint32_t it = perm[p];
+      below = median_key(f[(size_t)(6 + w.axis) * n + it], shape[it]) <= w.mmid ? 1u : 0u;
+    } else {
+      key = kNoW;
+    }
+  }
+  const uint32_t sum = run_reduce(below, key, [](uint32_t x, uint32_t y) { return x + y; });
+  if (run_head(key) && sum) atomicAdd(&wn[key].mcnt, sum);
+}
+__global__ void k_mupdate(WNode* wn, uint32_t m) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  WNode& w = wn[i];
+  if (w.kind != kMedian || !w.large || w.mlo == w.mhi) return;
+  if (w.mcnt >= (w.e - w.b) / 2u)
+    w.mhi = w.mmid;
+  else
+    w.mlo = w.mmid + 1ull;
+  w.mmid = w.mlo + (w.mhi - w.mlo) / 2ull;
+  w.mcnt = 0;
+}
+
 // flag = this position goes to the left child; exclusive prefix sums inside the block, the block's total on the side
-__global__ __launch_bounds__(256) void k_flags(const uint32_t* perm, const uint32_t* node_of, const float* f, uint32_t n,
-                                               const WNode* wn, const uint8_t* mflag, uint32_t* pre, uint8_t* flag,
+__global__ __launch_bounds__(256) void k_flags(const uint32_t* perm, const uint32_t* node_of, const float* f, const uint32_t* shape,
+                                               uint32_t n, const WNode* wn, const uint8_t* mflag, uint32_t* pre, uint8_t* flag,
                                                uint32_t* block_sum) {
   __shared__ uint32_t wave_sum[4];
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -468,7 +511,7 @@ __global__ __launch_bounds__(256) void k_flags(const uint32_t* perm, const uint3
     if (w.kind == kSplit)
       fl = bin_of(f[(size_t)(6 + w.axis) * n + perm[p]], w.lo_c[w.axis], w.scale[w.axis]) <= (int)w.split;
     else if (w.kind == kMedian)
-      fl = mflag[p];
+      fl = w.large ? (median_key(f[(size_t)(6 + w.axis) * n + perm[p]], shape[perm[p]]) <= w.mlo ? 1u : 0u) : mflag[p];
   }
   const unsigned long long b = __ballot(fl);
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -560,7 +603,7 @@ struct DevBuf {
 
 // The tree over the triangles of the subtree under reference node R, into `tb` as TreeBuilder::finish leaves it
 // (nodes: header, then the binary nodes in pre-order; tris in leaf order).  false: not built here (no device memory, a
-// HIP error, a non-finite triangle, a node that needs the median fallback): the caller uses TreeBuilder itself.
+// HIP error, a non-finite triangle): the caller uses TreeBuilder itself.
 inline bool build_tree(int device, const RtScene* s, uint32_t R, rtaccel::TreeBuilder& tb) {
   std::vector<uint32_t> tri, shape, owner;
   for (uint32_t i = R; i < s->nodes[R].skip; i++) {
@@ -628,10 +671,18 @@ inline bool build_tree(int device, const RtScene* s, uint32_t R, rtaccel::TreeBu
     hipLaunchKernelGGL(k_prep, dim3(mb), dim3(64), 0, st, d_w.p, m, d_bins.p);
     hipLaunchKernelGGL(k_bin, dim3(nb), dim3(256), 0, st, d_perm.p, d_node.p, d_f.p, n, d_w.p, d_bins.p);
     hipLaunchKernelGGL(k_split, dim3(mb), dim3(64), 0, st, d_w.p, m, d_bins.p, d_nodes.p, d_g.p, depth, d_mlist.p);
-    hipLaunchKernelGGL(k_median, dim3(std::min<uint32_t>(m, 2048u)), dim3(256), 0, st, d_perm.p, d_f.p, d_shape.p, n, d_w.p, d_mlist.p,
-                       d_g.p, d_mflag.p);
-    hipLaunchKernelGGL(k_flags, dim3(nb), dim3(256), 0, st, d_perm.p, d_node.p, d_f.p, n, d_w.p, d_mflag.p, d_pre.p, d_flag.p,
-                       d_bsum.p);
+    RT_DEV_TRY(hipMemcpyAsync(&g, d_g.p, sizeof(g), hipMemcpyDeviceToHost, st));
+    RT_DEV_TRY(hipStreamSynchronize(st));
+    if (g.n_large)  // object-median splits of large nodes (deep under a mesh close to what one tree can hold)
+      for (int round = 0; round < 64; round++) {
+        hipLaunchKernelGGL(k_mcount, dim3(nb), dim3(256), 0, st, d_perm.p, d_node.p, d_f.p, d_shape.p, n, d_w.p);
+        hipLaunchKernelGGL(k_mupdate, dim3(mb), dim3(64), 0, st, d_w.p, m);
+      }
+    if (g.n_median)
+      hipLaunchKernelGGL(k_median, dim3(std::min<uint32_t>(g.n_median, 2048u)), dim3(256), 0, st, d_perm.p, d_f.p, d_shape.p, n, d_w.p,
+                         d_mlist.p, d_g.p, d_mflag.p);
+    hipLaunchKernelGGL(k_flags, dim3(nb), dim3(256), 0, st, d_perm.p, d_node.p, d_f.p, d_shape.p, n, d_w.p, d_mflag.p, d_pre.p,
+                       d_flag.p, d_bsum.p);
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, d_bsum.p, nb);
     hipLaunchKernelGGL(k_children, dim3(mb), dim3(64), 0, st, d_w.p, m, d_w2.p, d_pre.p, d_flag.p, d_bsum.p, d_g.p);
     hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(256), 0, st, d_perm.p, d_node.p, n, d_w.p, d_pre.p, d_flag.p, d_bsum.p, d_perm2.p,
@@ -640,7 +691,7 @@ inline bool build_tree(int device, const RtScene* s, uint32_t R, rtaccel::TreeBu
     RT_DEV_TRY(hipMemcpyAsync(&g, d_g.p, sizeof(g), hipMemcpyDeviceToHost, st));
     RT_DEV_TRY(hipStreamSynchronize(st));
     if (g.bad || g.give_up) {
-      if (timing) std::fprintf(stderr, "device tree: declined at depth %d (%s)\n", depth, g.bad ? "non-finite triangle" : "median split of a large node");
+      if (timing) std::fprintf(stderr, "device tree: declined at depth %d (%s)\n", depth, g.bad ? "non-finite triangle" : "gave up");
       return false;
     }
     std::swap(d_perm.p, d_perm2.p);
@@ -660,7 +711,7 @@ inline bool build_tree(int device, const RtScene* s, uint32_t R, rtaccel::TreeBu
     }
     if (d_mlist.cap < (size_t)m && !d_mlist.ensure(2 * (size_t)m)) return false;
     RT_DEV_TRY(hipMemsetAsync(&d_g.p->n_next, 0, sizeof(uint32_t), st));
-    RT_DEV_TRY(hipMemsetAsync(&d_g.p->n_median, 0, sizeof(uint32_t), st));
+    RT_DEV_TRY(hipMemsetAsync(&d_g.p->n_median, 0, 2 * sizeof(uint32_t), st));  // n_median, n_large
   }
   stage("levels");
   const uint32_t n_nodes = g.n_nodes;

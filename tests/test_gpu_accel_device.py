@@ -91,12 +91,14 @@ def test_device_tree_equals_host_tree_on_the_bench_mesh():
     _compare(host.hip_lib(), ctx, fs, 871_200, exact_order=False)
 
 
-@pytest.mark.parametrize("seed,n", [(1, 20_000), (2, 70_001)])
+@pytest.mark.parametrize("seed,n", [(1, 20_000), (2, 70_001), (3, 2_000_000)])
 def test_device_tree_equals_host_tree_on_triangle_soup(seed, n):
+    """(2 M triangles: close to what one tree of 20 levels holds, so that already high in the tree only nearly even
+    splits leave room for the levels below and large nodes take the object median: k_mcount / k_mupdate.)"""
     w = _soup_world(seed, n)
     fs = w.flatten()
     ctx, _ = w.device_scene()
-    _compare(host.hip_lib(), ctx, fs, n)
+    _compare(host.hip_lib(), ctx, fs, n, exact_order=n < 1_000_000)
 
 
 def test_small_trees_stay_on_the_host():
