@@ -302,6 +302,10 @@ struct HGroup {
   // mtris is the copy of node `tmpl_node` of divide template `tmpl_id` (-1: not, or changed since): the flattener
   // finds the triangle run of such a group by this key instead of hashing the index sequence
   int tmpl_id = -1, tmpl_node = -1;
+  // the group and everything below it still hold exactly the triangles of node `sub_node` of template `sub_id` (its
+  // copy, possibly divided further or materialised: the same triangles), all transforms below the identity: its bounds
+  // are that node's `sub` box (make_bounds: the union of 871 k boxes, once per template instead of once per instance)
+  int sub_id = -1, sub_node = -1;
 };
 // The result of `divide` on a fresh mesh group (groups.rs:284-299), kept so that the next instance of the same mesh
 // with the same threshold is a copy of the tree instead of a second partition of 871 k triangles: the partition
@@ -309,6 +313,7 @@ struct HGroup {
 struct DivNode {
   std::vector<uint32_t> mtris;
   std::vector<int> children;  // indices into DivTemplate::nodes
+  Box sub;                    // union of the boxes of every triangle at or below the node
 };
 struct DivTemplate {
   std::vector<DivNode> nodes;  // [0] = the mesh group itself
@@ -520,6 +525,11 @@ struct RtbWorld {
   std::vector<std::unique_ptr<HMesh>> meshes;
   TriValueTable tri_values;
   std::map<std::pair<int, int>, DivTemplate> div_cache;  // (mesh, threshold) -> the divided tree
+  std::vector<const DivTemplate*> div_by_id;              // ... by DivTemplate::id (map nodes do not move)
+  // g gets something new (a shape, a child, a transform): it and every group above it stop being plain copies
+  void no_longer_template_bounds(int g) {
+    for (int a = g; a >= 0; a = groups[a].parent) groups[a].sub_id = groups[a].sub_node = -1;
+  }
   std::vector<HGroup> groups;
   std::vector<HCsg> csgs;
   std::vector<HUv> uvs;
@@ -645,6 +655,7 @@ struct RtbWorld {
   }
   Box make_bounds(int g) const {  // :176-188
     const HGroup& gr = groups[g];
+    if (gr.sub_id >= 0 && gr.parent >= 0) return div_by_id[gr.sub_id]->nodes[gr.sub_node].sub;
     Box bb;
     for (uint32_t s : gr.shapes) box_merge(bb, shapes[s].psb);
     if (!gr.mtris.empty()) {
@@ -745,6 +756,7 @@ struct RtbWorld {
   void instantiate(int g, const DivTemplate& t, int node) {
     groups[g].mtris = t.nodes[node].mtris;
     groups[g].tmpl_id = t.id, groups[g].tmpl_node = node;
+    groups[g].sub_id = t.id, groups[g].sub_node = node;
     groups[g].fresh_mesh = false;
     for (int k : t.nodes[node].children) {
       const int c = new_group();
@@ -761,9 +773,13 @@ struct RtbWorld {
   void divide_template(const HMesh& m, std::vector<uint32_t> tris, int threshold, DivTemplate& t, int par) const {
     const int me = (int)t.nodes.size();
     t.nodes.emplace_back();
+    {
+      Box all;
+      for (uint32_t q : tris) box_merge(all, m.box[q]);
+      t.nodes[me].sub = all;
+    }
     if (threshold <= (int)tris.size()) {
-      Box bb;
-      for (uint32_t q : tris) box_merge(bb, m.box[q]);
+      const Box bb = t.nodes[me].sub;
       Box lb, rb;
       box_split(bb, &lb, &rb);
       std::vector<uint32_t> lt, rt, keep;
@@ -822,6 +838,7 @@ struct RtbWorld {
         divide_template(*meshes[groups[g].mesh], groups[g].mtris, threshold, t, 4);
         t.id = (int)div_cache.size();
         it = div_cache.emplace(key, std::move(t)).first;
+        div_by_id.push_back(&it->second);
         if (timing) std::fprintf(stderr, "divide: template of %zu groups %.1f ms\n", it->second.nodes.size(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
         t0 = std::chrono::steady_clock::now();
       }
@@ -1467,6 +1484,7 @@ int rth_shape_new(RtbWorld* w, int kind, const RtbXfOp* ops, int nops, const Rtb
 int rth_group_new(RtbWorld* w, const RtbXfOp* ops, int nops) {
   int g = w->new_group();
   w->groups[g].xf = compose(ops, nops);
+  w->no_longer_template_bounds(g);
   if (!m4_inverse(w->groups[g].xf, &w->groups[g].inv)) return fail(w, "group transform is not invertible");
   w->touch();
   return g;
@@ -1482,6 +1500,7 @@ int rth_group_add_shape(RtbWorld* w, int g, int shape) {
   if (g < 0 || g >= (int)w->groups.size() || shape < 0 || shape >= (int)w->shapes.size())
     return fail(w, "bad handle");
   w->materialise(g);                             // a mesh group that also gets other shapes holds shapes only
+  w->no_longer_template_bounds(g);
   uint32_t s = w->clone_shape((uint32_t)shape);  // groups.rs:80-85: the group owns a copy
   w->shapes[s].parent = g;
   w->groups[g].shapes.push_back(s);
@@ -1492,6 +1511,7 @@ int rth_group_add_child(RtbWorld* w, int g, int child) {
   if (g < 0 || g >= (int)w->groups.size() || child < 0 || child >= (int)w->groups.size())
     return fail(w, "bad group handle");
   w->attach_child(g, child);
+  w->no_longer_template_bounds(g);
   w->touch();
   return 0;
 }
@@ -1673,6 +1693,7 @@ int rth_group_add_mesh(RtbWorld* w, int g, const RtbMaterial* material, const fl
   for (int t = 0; t < ntriangles; t++) cg.mtris[t] = (uint32_t)t;
   cg.fresh_mesh = true;
   w->attach_child(g, child);
+  w->no_longer_template_bounds(g);
   w->touch();
   return child;
 }
@@ -1713,8 +1734,11 @@ int rth_world_add_shape(RtbWorld* w, int shape) {
 int rth_world_add_group(RtbWorld* w, int g, int cache_bounds) {
   if (g < 0 || g >= (int)w->groups.size()) return fail(w, "bad group handle");
   if (cache_bounds) {  // groups.rs:190-196
+    const auto t0 = std::chrono::steady_clock::now();
     w->groups[g].bounds = w->make_bounds(g);
     w->groups[g].cached = true;
+    if (std::getenv("RT_TIMING"))
+      std::fprintf(stderr, "world_add_group: bounds %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
   }
   w->world_groups.push_back(g);
   w->touch();
