@@ -786,19 +786,22 @@ __device__ __forceinline__ uint32_t* aux_stack() {
 }
 // Conservative slab test against a box widened by `pad`: never reports a miss for a line that comes
 // within the padding of the box contents; NaNs (0 * inf) count as "inside".
-__device__ __forceinline__ bool aux_box(V3 o, V3 inv, float pad, f4n mn, f4n mx, float lo, float hi,
-                                        float& tnear) {
-  float ax = ((mn.x - pad) - o.x) * inv.x, bx = ((mx.x + pad) - o.x) * inv.x;
-  float ay = ((mn.y - pad) - o.y) * inv.y, by = ((mx.y + pad) - o.y) * inv.y;
-  float az = ((mn.z - pad) - o.z) * inv.z, bz = ((mx.z + pad) - o.z) * inv.z;
+//   o_lo = o + pad meets the box minima, o_hi = o - pad the maxima: (mn - pad) - o taken as mn - (o + pad), six
+//   additions a node instead of six a box (either way two roundings of coordinate size before the product: what the
+//   relative margin below and the static padding of rt_accel.h are there for).
+//   Margin: a miss is reported only where tn - 2e-6|tn| > tf + 2e-6|tf|, tn - 2e-6|tn| > hi or tf + 2e-6|tf| < lo
+//   would hold as well: tn against tf + 5e-6|tf|, and against the limits widened by 5e-6 of themselves (aux_node4, once
+//   a node).  fmax drops the NaN of -inf + inf (a ray parallel to a slab it lies outside of has tn = +inf or
+//   tf = -inf and must stay a miss, not turn into "NaN = inside").
+__device__ __forceinline__ bool aux_box(V3 o_lo, V3 o_hi, V3 inv, f4n mn, f4n mx, float lo_w, float hi_w, float& tnear) {
+  float ax = (mn.x - o_lo.x) * inv.x, bx = (mx.x - o_hi.x) * inv.x;
+  float ay = (mn.y - o_lo.y) * inv.y, by = (mx.y - o_hi.y) * inv.y;
+  float az = (mn.z - o_lo.z) * inv.z, bz = (mx.z - o_hi.z) * inv.z;
   float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz));
   float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz));
-  // relative slack; fmin/fmax drop the NaN of inf - inf (a ray parallel to a slab it lies outside of has
-  // tn = +inf or tf = -inf and must stay a miss, not turn into "NaN = inside")
-  tn = __builtin_fminf(tn, tn - 2e-6f * __builtin_fabsf(tn));
-  tf = __builtin_fmaxf(tf, tf + 2e-6f * __builtin_fabsf(tf));
+  const float tfw = __builtin_fmaxf(tf, __builtin_fmaf(5e-6f, __builtin_fabsf(tf), tf));
   tnear = tn;
-  return !(tn > tf) && !(tn > hi) && !(tf < lo);
+  return !(tn > tfw) && !(tn > hi_w) && !(tf < lo_w);
 }
 // One visit of a 4-wide node (rt_accel.h Layout): the boxes of its 2-4 children, widened for this ray by the node's
 // normal-cone bound (see aux_intersect), against the t range [lo0, lim].  Returns the nearest child that is hit and
@@ -830,10 +833,12 @@ __device__ __forceinline__ uint32_t aux_node4(const Scene& sc, const uint32_t id
   const float lo = lo0 - tpad;
   const float hi = (lim + 1e-5f * __builtin_fabsf(lim)) + tpad;
   float t0, t1, t2, t3;
-  const bool h0 = aux_box(o, inv, pad, q0, q1, lo, hi, t0);
-  const bool h1 = aux_box(o, inv, pad, q2, q3, lo, hi, t1);
-  const bool h2 = aux_box(o, inv, pad, q4, q5, lo, hi, t2) && r2 != RT_AUX_NONE;
-  const bool h3 = aux_box(o, inv, pad, q6, q7, lo, hi, t3) && r3 != RT_AUX_NONE;
+  const V3 o_lo = v3(o.x + pad, o.y + pad, o.z + pad), o_hi = v3(o.x - pad, o.y - pad, o.z - pad);
+  const float lo_w = __builtin_fmaf(-5e-6f, __builtin_fabsf(lo), lo), hi_w = __builtin_fmaf(5e-6f, __builtin_fabsf(hi), hi);
+  const bool h0 = aux_box(o_lo, o_hi, inv, q0, q1, lo_w, hi_w, t0);
+  const bool h1 = aux_box(o_lo, o_hi, inv, q2, q3, lo_w, hi_w, t1);
+  const bool h2 = aux_box(o_lo, o_hi, inv, q4, q5, lo_w, hi_w, t2) && r2 != RT_AUX_NONE;
+  const bool h3 = aux_box(o_lo, o_hi, inv, q6, q7, lo_w, hi_w, t3) && r3 != RT_AUX_NONE;
   const float inf = __builtin_inff();
   if (!h0) r0 = RT_AUX_NONE, t0 = inf;
   if (!h1) r1 = RT_AUX_NONE, t1 = inf;
