@@ -306,6 +306,9 @@ struct HGroup {
   // copy, possibly divided further or materialised: the same triangles), all transforms below the identity: its bounds
   // are that node's `sub` box (make_bounds: the union of 871 k boxes, once per template instead of once per instance)
   int sub_id = -1, sub_node = -1;
+  // this group is node 0 of an untouched copy of template `inst_tmpl`: every group below is what `instantiate` made
+  // (nothing added, moved, divided again or given a transform since), so the flattener emits the subtree from the template
+  int inst_tmpl = -1;
 };
 // The result of `divide` on a fresh mesh group (groups.rs:284-299), kept so that the next instance of the same mesh
 // with the same threshold is a copy of the tree instead of a second partition of 871 k triangles: the partition
@@ -395,6 +398,11 @@ struct ClassTable {
   uint32_t fresh() {  // a new class id that no key maps to (the caller keeps its own index to it)
     where.push_back(0);
     return next++;
+  }
+  uint32_t fresh_n(uint32_t n) {  // n of them in a row; returns the first
+    where.insert(where.end(), n, 0);
+    next += n;
+    return next - n;
   }
   uint32_t get(const KeyBuilder& k) {
     if (k.nan) return RT_VCLASS_NEVER;
@@ -499,11 +507,31 @@ struct TriValueTable {
   }
 };
 
+// resize() of the big arrays leaves the new elements as they are (every one is written by the fills of the flattener,
+// in pieces on threads): zeroing 5 M shape records first was a sixth of the flatten
+template <class T>
+struct RawAlloc : std::allocator<T> {
+  template <class U>
+  struct rebind {
+    typedef RawAlloc<U> other;
+  };
+  RawAlloc() = default;
+  template <class U>
+  RawAlloc(const RawAlloc<U>&) {}
+  template <class U>
+  void construct(U* p) {
+    ::new ((void*)p) U;
+  }
+  template <class U, class... A>
+  void construct(U* p, A&&... a) {
+    ::new ((void*)p) U(std::forward<A>(a)...);
+  }
+};
 struct Flat {
   std::vector<RtXform> xforms;
-  std::vector<RtShape> shapes;
-  std::vector<RtTriGeom> tri_geom;
-  std::vector<RtTriNormals> tri_normals;
+  std::vector<RtShape, RawAlloc<RtShape>> shapes;
+  std::vector<RtTriGeom, RawAlloc<RtTriGeom>> tri_geom;
+  std::vector<RtTriNormals, RawAlloc<RtTriNormals>> tri_normals;
   std::vector<RtNode> nodes;
   std::vector<RtCsgNode> csg_nodes;
   std::vector<RtCsgRoot> csg_roots;
@@ -528,7 +556,11 @@ struct RtbWorld {
   std::vector<const DivTemplate*> div_by_id;              // ... by DivTemplate::id (map nodes do not move)
   // g gets something new (a shape, a child, a transform): it and every group above it stop being plain copies
   void no_longer_template_bounds(int g) {
-    for (int a = g; a >= 0; a = groups[a].parent) groups[a].sub_id = groups[a].sub_node = -1;
+    for (int a = g; a >= 0; a = groups[a].parent) groups[a].sub_id = groups[a].sub_node = groups[a].inst_tmpl = -1;
+  }
+  // g changes in a way that leaves the triangles below its ancestors where they are (a transform, another divide)
+  void no_longer_template_copy(int g) {
+    for (int a = g; a >= 0; a = groups[a].parent) groups[a].inst_tmpl = -1;
   }
   std::vector<HGroup> groups;
   std::vector<HCsg> csgs;
@@ -626,6 +658,7 @@ struct RtbWorld {
   void materialise(int g) {
     HGroup& gr = groups[g];
     if (gr.mtris.empty()) return;
+    no_longer_template_copy(g);
     const HMesh& m = *meshes[gr.mesh];
     std::vector<uint32_t> made;
     made.reserve(gr.mtris.size());
@@ -753,18 +786,39 @@ struct RtbWorld {
     }
     return me;
   }
-  void instantiate(int g, const DivTemplate& t, int node) {
-    groups[g].mtris = t.nodes[node].mtris;
-    groups[g].tmpl_id = t.id, groups[g].tmpl_node = node;
-    groups[g].sub_id = t.id, groups[g].sub_node = node;
-    groups[g].fresh_mesh = false;
-    for (int k : t.nodes[node].children) {
-      const int c = new_group();
-      groups[c].mesh = groups[g].mesh;
-      groups[c].mmat = groups[g].mmat;
-      attach_child(g, c);
-      instantiate(c, t, k);
-    }
+  // The copy of a template under group g.  The template's nodes are in pre-order and so are the groups a recursive copy
+  // would make (a child is created, then everything below it): node k > 0 becomes group base + k - 1, and the copy is
+  // one growth of the table and a fill in pieces on threads.
+  void instantiate(int g, const DivTemplate& t) {
+    const size_t n = t.nodes.size();
+    const int base = (int)groups.size();
+    groups.resize(groups.size() + n - 1);
+    const int mesh = groups[g].mesh;
+    const RtbMaterial mmat = groups[g].mmat;
+    auto group_of = [&](size_t k) { return k == 0 ? g : base + (int)k - 1; };
+    auto fill = [&](size_t k0, size_t k1) {
+      for (size_t k = k0; k < k1; k++) {
+        HGroup& gr = groups[group_of(k)];
+        const DivNode& nd = t.nodes[k];
+        gr.mtris = nd.mtris;
+        gr.tmpl_id = t.id, gr.tmpl_node = (int)k;
+        gr.sub_id = t.id, gr.sub_node = (int)k;
+        gr.fresh_mesh = false;
+        gr.mesh = mesh;
+        gr.mmat = mmat;
+        gr.children.resize(nd.children.size());
+        for (size_t c = 0; c < nd.children.size(); c++) {
+          gr.children[c] = group_of((size_t)nd.children[c]);
+          groups[gr.children[c]].parent = group_of(k);  // (every node is the child of exactly one)
+        }
+      }
+    };
+    const size_t nt = n >= 4096 ? std::min<size_t>(8, std::max(1u, std::thread::hardware_concurrency())) : 1;
+    std::vector<std::thread> th;
+    for (size_t i = 1; i < nt; i++) th.emplace_back(fill, n * i / nt, n * (i + 1) / nt);
+    fill(0, n / nt);
+    for (auto& x : th) x.join();
+    groups[g].inst_tmpl = t.id;
   }
   // `divide` (groups.rs:284-299) of a group that holds only triangles `tris` of mesh `m`, as a template: partition if
   // threshold <= len (groups.rs:285), attach the non-empty halves, divide them.  Every group met on the way has no
@@ -844,10 +898,11 @@ struct RtbWorld {
       }
       if (groups.capacity() < groups.size() + it->second.nodes.size())  // one growth for the whole copy, with room for the next
         groups.reserve(std::max(groups.capacity() * 2, groups.size() + 2 * it->second.nodes.size()));
-      instantiate(g, it->second, 0);
+      instantiate(g, it->second);
       if (timing) std::fprintf(stderr, "divide: instance %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
       return;
     }
+    no_longer_template_copy(g);
     if (threshold <= group_len(g)) {
       int L, R;
       partition(g, &L, &R);
@@ -882,6 +937,7 @@ struct Flattener {
   // shape, without hashing the 100-byte value of each of millions of mesh triangles per instance.
   ClassTable triple_classes;
   std::vector<std::vector<uint32_t>> triple_map;
+  std::vector<size_t> triple_set;  // per triple: how many entries of its map hold a class
   static constexpr uint32_t kUnset = 0xFFFFFFFEu;
   // Triangle data already emitted, by (mesh, sequence of triangle indices): instances of one mesh, divided the same
   // way, share their tri_geom / tri_normals entries (a node's own triangles are a contiguous run of them).
@@ -896,20 +952,84 @@ struct Flattener {
 
   double t_loop = 0, t_run = 0;
   Flattener(RtbWorld& w_, Flat& f_) : w(w_), f(f_) {}
+  // What the walk over the groups leaves for later: the shape records of a mesh group's triangles and the triangle
+  // data of a run, both plain copies into places fixed by the walk -- done in pieces on threads once the walk is over
+  // (run_fills).  What decides a number (value classes, indices) is done by the walk itself, in its order.
+  struct ShapeFill {
+    size_t base;
+    int mesh;
+    const std::vector<uint32_t>* mtris;
+    uint32_t node, first_tri, mat_index;
+    uint32_t tid_flat, tid_smooth;  // RT_VCLASS_NEVER: no value class for any of them
+  };
+  struct TriFill {
+    uint32_t first;
+    int mesh;
+    const std::vector<uint32_t>* seq;
+  };
+  std::vector<ShapeFill> shape_fills;
+  std::vector<TriFill> tri_fills;
+  void fill_shapes(const ShapeFill& sf) {
+    const std::vector<uint32_t>& mtris = *sf.mtris;
+    const HMesh& m = *w.meshes[sf.mesh];
+    const uint32_t* map_flat = sf.tid_flat != RT_VCLASS_NEVER ? triple_map[sf.tid_flat].data() : nullptr;
+    const uint32_t* map_smooth = sf.tid_flat != RT_VCLASS_NEVER ? triple_map[sf.tid_smooth].data() : nullptr;
+    for (size_t k = 0; k < mtris.size(); k++) {
+      const uint32_t t = mtris[k];
+      RtShape r{};
+      r.kind_flags = m.smooth[t] | RT_SHAPE_SHADOW;
+      r.xform = 0;
+      r.material = sf.mat_index;
+      r.parent = (int32_t)sf.node;
+      const uint32_t gid = m.gid[t];
+      r.vclass = (map_flat && gid != RT_VCLASS_NEVER) ? (m.smooth[t] == RTB_SMOOTH_TRIANGLE ? map_smooth : map_flat)[gid] : RT_VCLASS_NEVER;
+      r.prim = sf.first_tri + (uint32_t)k;
+      r.mn = -kInf;
+      r.mx = kInf;
+      f.shapes[sf.base + k] = r;
+    }
+  }
+  void fill_tris(const TriFill& tf) {
+    const HMesh& m = *w.meshes[tf.mesh];
+    for (size_t k = 0; k < tf.seq->size(); k++) fill_tri(m.tris[(*tf.seq)[k]], &f.tri_geom[tf.first + k], &f.tri_normals[tf.first + k]);
+  }
+  void run_fills() {
+    size_t total = 0;
+    for (const ShapeFill& sf : shape_fills) total += sf.mtris->size();
+    for (const TriFill& tf : tri_fills) total += 2 * tf.seq->size();
+    const unsigned nt = total >= (1u << 16) ? std::min(16u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
+    // pieces of about equal weight, in task order (neighbouring tasks write neighbouring memory)
+    auto piece = [&](unsigned i) {
+      const size_t lo = total * i / nt, hi = total * (i + 1) / nt;
+      size_t at = 0;
+      for (const ShapeFill& sf : shape_fills) {
+        if (at >= lo && at < hi) fill_shapes(sf);
+        at += sf.mtris->size();
+      }
+      for (const TriFill& tf : tri_fills) {
+        if (at >= lo && at < hi) fill_tris(tf);
+        at += 2 * tf.seq->size();
+      }
+    };
+    std::vector<std::thread> th;
+    for (unsigned i = 1; i < nt; i++) th.emplace_back(piece, i);
+    piece(0);
+    for (auto& x : th) x.join();
+  }
 
   uint32_t triple_id(uint32_t kind, const M4& xf, uint32_t mclass, bool shadow) {
     if (mclass == RT_VCLASS_NEVER) return RT_VCLASS_NEVER;
     KeyBuilder k;
     k.u(kind), k.fs(xf.a, 16), k.u(mclass), k.u(shadow ? 1 : 0);
     const uint32_t tid = triple_classes.get(k);
-    if (tid != RT_VCLASS_NEVER && tid >= triple_map.size()) triple_map.resize(tid + 1);
+    if (tid != RT_VCLASS_NEVER && tid >= triple_map.size()) triple_map.resize(tid + 1), triple_set.resize(tid + 1, 0);
     return tid;
   }
   uint32_t tri_vclass(uint32_t tid, uint32_t gid) {
     if (tid == RT_VCLASS_NEVER || gid == RT_VCLASS_NEVER) return RT_VCLASS_NEVER;
     std::vector<uint32_t>& mp = triple_map[tid];
     if (gid >= mp.size()) mp.resize(std::max<size_t>(gid + 1, w.tri_values.rep.size()), kUnset);
-    if (mp[gid] == kUnset) mp[gid] = shape_classes.fresh();
+    if (mp[gid] == kUnset) mp[gid] = shape_classes.fresh(), triple_set[tid]++;
     return mp[gid];
   }
   static void fill_tri(const HTri& t, RtTriGeom* g, RtTriNormals* n) {
@@ -922,15 +1042,60 @@ struct Flattener {
     n->n2[0] = t.n2.x, n->n2[1] = t.n2.y, n->n2[2] = t.n2.z;
     n->n3[0] = t.n3.x, n->n3[1] = t.n3.y, n->n3[2] = t.n3.z;
   }
-  std::unordered_map<uint64_t, Run> tmpl_runs;  // (divide template, node) -> its run
-  const Run& geometry_run(int mesh, const std::vector<uint32_t>& seq, int tmpl_id, int tmpl_node) {
-    if (tmpl_id >= 0) {
-      const uint64_t key = ((uint64_t)(uint32_t)tmpl_id << 32) | (uint32_t)tmpl_node;
-      auto it = tmpl_runs.find(key);
-      if (it != tmpl_runs.end()) return it->second;
-      const Run& r = geometry_run(mesh, seq, -1, -1);
-      return tmpl_runs.emplace(key, r).first->second;
+  // A divide template as the flattener needs it, made when its first copy is met: the run of every node (all of them
+  // at once, in the template's pre-order = the order a walk over a copy meets them), and what a walk over an untouched
+  // copy would compute for every node -- parents, depths, subtree ends, shape offsets, boxes, flags.
+  struct TmplFlat {
+    std::vector<Run> run;
+    std::vector<uint32_t> size_before;  // tri_geom.size() when the node's run was asked for (first_tri of a node without triangles)
+    std::vector<int> parent, depth, end;
+    std::vector<uint32_t> prefix;       // triangles of the nodes before k in pre-order
+    std::vector<Box> box;               // merge of the node's run box and its children's boxes, in that order
+    std::vector<uint32_t> flags;
+    // distinct (geometry class, smooth) of the whole template in the order a walk first meets them (bit 31: smooth)
+    std::vector<uint32_t> first_met;
+    bool first_met_done = false;
+  };
+  std::unordered_map<int, TmplFlat> tmpl_flat;
+  TmplFlat& template_flat(int tmpl_id, int mesh) {
+    auto it = tmpl_flat.find(tmpl_id);
+    if (it != tmpl_flat.end()) return it->second;
+    const DivTemplate& t = *w.div_by_id[tmpl_id];
+    const size_t n = t.nodes.size();
+    TmplFlat tf;
+    tf.run.reserve(n);
+    tf.size_before.resize(n);
+    tf.parent.assign(n, -1);
+    tf.depth.assign(n, 0);
+    tf.end.assign(n, 0);
+    tf.prefix.assign(n + 1, 0);
+    tf.box.resize(n);
+    tf.flags.resize(n);
+    for (size_t k = 0; k < n; k++) {
+      tf.size_before[k] = (uint32_t)f.tri_geom.size();
+      if (t.nodes[k].mtris.empty())
+        tf.run.push_back(Run{mesh, &t.nodes[k].mtris, tf.size_before[k], Box{}});
+      else
+        tf.run.push_back(geometry_run(mesh, t.nodes[k].mtris, -1, -1));
+      tf.prefix[k + 1] = tf.prefix[k] + (uint32_t)t.nodes[k].mtris.size();
+      for (int c : t.nodes[k].children) tf.parent[c] = (int)k, tf.depth[c] = tf.depth[k] + 1;
     }
+    for (size_t k = n; k-- > 0;) {
+      const DivNode& nd = t.nodes[k];
+      tf.end[k] = nd.children.empty() ? (int)k + 1 : tf.end[nd.children.back()];
+      Box bb;  // emit_group's bb and tb of a group with a parent and identity children: the same merges
+      if (!nd.mtris.empty()) box_merge(bb, tf.run[k].box);
+      for (int c : nd.children) box_merge(bb, tf.box[c]);
+      tf.box[k] = bb;
+      const bool encloses = bb.lo.x >= bb.lo.x && bb.lo.y >= bb.lo.y && bb.lo.z >= bb.lo.z && bb.hi.x <= bb.hi.x &&
+                            bb.hi.y <= bb.hi.y && bb.hi.z <= bb.hi.z;  // false if any NaN
+      const bool empty = bb.lo.x > bb.hi.x && bb.lo.y > bb.hi.y && bb.lo.z > bb.hi.z;
+      tf.flags[k] = (!nd.mtris.empty() ? RT_NODE_ALL_TRIS : 0u) | ((encloses || empty) ? RT_NODE_PRUNABLE : 0u);
+    }
+    return tmpl_flat.emplace(tmpl_id, std::move(tf)).first->second;
+  }
+  const Run& geometry_run(int mesh, const std::vector<uint32_t>& seq, int tmpl_id, int tmpl_node) {
+    if (tmpl_id >= 0) return template_flat(tmpl_id, mesh).run[tmpl_node];
     uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)mesh;
     for (uint32_t t : seq) {
       h = (h ^ t) * 0xFF51AFD7ED558CCDull;
@@ -945,10 +1110,8 @@ struct Flattener {
     f.tri_geom.resize(first + seq.size());
     f.tri_normals.resize(first + seq.size());
     Box mb;
-    for (size_t k = 0; k < seq.size(); k++) {
-      fill_tri(m.tris[seq[k]], &f.tri_geom[first + k], &f.tri_normals[first + k]);
-      box_merge(mb, m.box[seq[k]]);
-    }
+    for (size_t k = 0; k < seq.size(); k++) box_merge(mb, m.box[seq[k]]);
+    tri_fills.push_back(TriFill{first, mesh, &seq});
     bucket.push_back(Run{mesh, &seq, first, mb});
     return bucket.back();
   }
@@ -1159,6 +1322,113 @@ struct Flattener {
     return (int)f.csg_nodes.size() - 1;
   }
 
+  // material index and the value-class tables of a mesh group's triangles (flat, smooth), sized for the mesh
+  void mesh_classes(const RtbMaterial& mmat, uint32_t* mat_index, uint32_t* tid_flat, uint32_t* tid_smooth) {
+    uint32_t mclass;
+    material(mmat, mat_index, &mclass);
+    auto tids = mesh_triples.find(mclass);
+    if (tids == mesh_triples.end()) {
+      const M4 ident = m4_identity();
+      tids = mesh_triples.emplace(mclass, std::make_pair(triple_id(RTB_TRIANGLE, ident, mclass, true),
+                                                         triple_id(RTB_SMOOTH_TRIANGLE, ident, mclass, true))).first;
+    }
+    *tid_flat = tids->second.first, *tid_smooth = tids->second.second;
+    const size_t n_gid = w.tri_values.rep.size();
+    if (*tid_flat != RT_VCLASS_NEVER) {
+      if (triple_map[*tid_flat].size() < n_gid) triple_map[*tid_flat].resize(n_gid, kUnset);
+      if (triple_map[*tid_smooth].size() < n_gid) triple_map[*tid_smooth].resize(n_gid, kUnset);
+    }
+  }
+  // value classes of a run of mesh triangles, in the order the shapes are met (the numbering is part of the output);
+  // the records themselves are written later (fill_shapes)
+  void class_pass(const HMesh& m, const std::vector<uint32_t>& mtris, uint32_t tid_flat, uint32_t tid_smooth) {
+    if (tid_flat == RT_VCLASS_NEVER) return;
+    uint32_t* map_flat = triple_map[tid_flat].data();
+    uint32_t* map_smooth = triple_map[tid_smooth].data();
+    for (size_t k = 0; k < mtris.size(); k++) {
+      const uint32_t t = mtris[k];
+      const uint32_t gid = m.gid[t];
+      if (gid != RT_VCLASS_NEVER) {
+        const bool smooth = m.smooth[t] == RTB_SMOOTH_TRIANGLE;
+        uint32_t& slot = (smooth ? map_smooth : map_flat)[gid];
+        if (slot == kUnset) {
+          slot = shape_classes.fresh();
+          triple_set[smooth ? tid_smooth : tid_flat]++;
+        }
+      }
+    }
+  }
+  // ... of every node of an untouched template copy at once (what class_pass would do node after node in pre-order).
+  // Into tables nothing has been entered into yet -- a material met for the first time, as with every dragon of
+  // dragons.yaml -- the classes are the template's distinct geometries in the order a walk first meets them, numbered
+  // from the next free class: that order is kept with the template, and the next copy writes it down instead of
+  // looking at 871 k triangles again.
+  void class_pass_instance(const HMesh& m, const DivTemplate& t, TmplFlat& tf, uint32_t tid_flat, uint32_t tid_smooth) {
+    if (tid_flat == RT_VCLASS_NEVER) return;
+    if (triple_set[tid_flat] != 0 || triple_set[tid_smooth] != 0) {
+      for (const DivNode& nd : t.nodes) class_pass(m, nd.mtris, tid_flat, tid_smooth);
+      return;
+    }
+    if (!tf.first_met_done) {
+      std::vector<uint8_t> seen(w.tri_values.rep.size(), 0);  // bit 0: as a flat triangle, bit 1: as a smooth one
+      for (const DivNode& nd : t.nodes)
+        for (uint32_t q : nd.mtris) {
+          const uint32_t gid = m.gid[q];
+          if (gid == RT_VCLASS_NEVER) continue;
+          const bool smooth = m.smooth[q] == RTB_SMOOTH_TRIANGLE;
+          const uint8_t bit = smooth ? 2 : 1;
+          if (seen[gid] & bit) continue;
+          seen[gid] |= bit;
+          tf.first_met.push_back(gid | (smooth ? 0x80000000u : 0u));
+        }
+      tf.first_met_done = true;
+    }
+    uint32_t* map_flat = triple_map[tid_flat].data();
+    uint32_t* map_smooth = triple_map[tid_smooth].data();
+    const uint32_t base = shape_classes.fresh_n((uint32_t)tf.first_met.size());
+    for (size_t i = 0; i < tf.first_met.size(); i++) {
+      const uint32_t e = tf.first_met[i];
+      const bool smooth = (e & 0x80000000u) != 0u;
+      (smooth ? map_smooth : map_flat)[e & 0x7FFFFFFFu] = base + (uint32_t)i;
+      triple_set[smooth ? tid_smooth : tid_flat]++;
+    }
+  }
+  // The groups below the root of an untouched template copy (HGroup::inst_tmpl): node k of the template is node
+  // idx + k here, its shapes follow the root's by prefix[k]; everything else a walk would have found out about it is
+  // in the TmplFlat.  `created`: this copy is the one that made the template's runs (a walk would have seen tri_geom
+  // grow node by node).
+  void emit_instance_below(int mesh, const DivTemplate& t, const TmplFlat& tf, uint32_t idx, size_t shape_base, bool created,
+                           uint32_t mat_index, uint32_t tid_flat, uint32_t tid_smooth) {
+    const size_t n = t.nodes.size();
+    f.nodes.resize(idx + n);
+    true_box.resize(idx + n);
+    f.shapes.resize(shape_base + tf.prefix[n]);
+    const int32_t next_xf = f.nodes[idx].next_xf;
+    const uint32_t idrun = f.nodes[idx].idrun;
+    const uint32_t tri_now = (uint32_t)f.tri_geom.size();
+    for (size_t k = 1; k < n; k++) {
+      const DivNode& nd = t.nodes[k];
+      RtNode nn{};
+      const Box& bb = tf.box[k];
+      nn.bmin[0] = bb.lo.x, nn.bmin[1] = bb.lo.y, nn.bmin[2] = bb.lo.z;
+      nn.bmax[0] = bb.hi.x, nn.bmax[1] = bb.hi.y, nn.bmax[2] = bb.hi.z;
+      nn.xform = 0;
+      nn.flags = tf.flags[k];
+      nn.first_shape = (uint32_t)(shape_base + tf.prefix[k]);
+      nn.n_shapes = (uint32_t)nd.mtris.size();
+      nn.skip = idx + (uint32_t)tf.end[k];
+      nn.parent = (int32_t)(idx + (uint32_t)tf.parent[k]);
+      nn.first_tri = !nd.mtris.empty() ? tf.run[k].first_tri : created ? tf.size_before[k] : tri_now;
+      nn.next_xf = next_xf;
+      nn.idrun = idrun + (uint32_t)tf.depth[k];
+      nn.n_children = (uint32_t)nd.children.size();
+      f.nodes[idx + k] = nn;
+      true_box[idx + k] = bb;
+      if (!nd.mtris.empty())
+        shape_fills.push_back(ShapeFill{shape_base + tf.prefix[k], mesh, &nd.mtris, idx + (uint32_t)k, tf.run[k].first_tri, mat_index, tid_flat, tid_smooth});
+    }
+  }
+
   // groups depth-first; returns the node index
   uint32_t emit_group(int g, int parent_node, Box* bounds_out, Box* true_out) {
     uint32_t idx = (uint32_t)f.nodes.size();
@@ -1179,54 +1449,36 @@ struct Flattener {
       box_merge(tb, w.true_psb(hs));
       box_merge(bb, hs.psb);
     }
+    // the root of an untouched copy of a divide template: the groups below come from the template (emit_instance_below)
+    const DivTemplate* inst = nullptr;
+    TmplFlat* inst_flat = nullptr;
+    bool inst_created = false;
+    if (gr.inst_tmpl >= 0 && gr.tmpl_id == gr.inst_tmpl && gr.tmpl_node == 0 && gr.shapes.empty() && gr.mesh >= 0 &&
+        gr.children.size() == w.div_by_id[gr.inst_tmpl]->nodes[0].children.size()) {
+      inst = w.div_by_id[gr.inst_tmpl];
+      inst_created = tmpl_flat.find(gr.inst_tmpl) == tmpl_flat.end();
+      inst_flat = &template_flat(gr.inst_tmpl, gr.mesh);
+    }
+    uint32_t mat_index = 0, tid_flat = RT_VCLASS_NEVER, tid_smooth = RT_VCLASS_NEVER;
+    if (inst || !gr.mtris.empty()) mesh_classes(gr.mmat, &mat_index, &tid_flat, &tid_smooth);
+    if (inst) {
+      auto T0 = std::chrono::steady_clock::now();
+      class_pass_instance(*w.meshes[gr.mesh], *inst, *inst_flat, tid_flat, tid_smooth);
+      t_loop += std::chrono::duration<double>(std::chrono::steady_clock::now() - T0).count();
+      if (std::getenv("RT_TIMING")) std::fprintf(stderr, "flatten: instance classes %.1f ms (created %d)\n", 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - T0).count(), (int)inst_created);
+    }
     if (!gr.mtris.empty()) {  // the triangles of a mesh group, in bulk (a group holds these or shapes, never both)
       const HMesh& m = *w.meshes[gr.mesh];
       auto T1 = std::chrono::steady_clock::now();
       const Run& run = geometry_run(gr.mesh, gr.mtris, gr.tmpl_id, gr.tmpl_node);
       t_run += std::chrono::duration<double>(std::chrono::steady_clock::now() - T1).count();
       first_tri = run.first_tri;
-      uint32_t mat_index, mclass;
-      material(gr.mmat, &mat_index, &mclass);
-      auto tids = mesh_triples.find(mclass);
-      if (tids == mesh_triples.end()) {
-        const M4 ident = m4_identity();
-        tids = mesh_triples.emplace(mclass, std::make_pair(triple_id(RTB_TRIANGLE, ident, mclass, true),
-                                                           triple_id(RTB_SMOOTH_TRIANGLE, ident, mclass, true))).first;
-      }
-      const uint32_t tid_flat = tids->second.first, tid_smooth = tids->second.second;
-      uint32_t* map_flat = nullptr;
-      uint32_t* map_smooth = nullptr;
-      const size_t n_gid = w.tri_values.rep.size();
-      if (tid_flat != RT_VCLASS_NEVER) {
-        if (triple_map[tid_flat].size() < n_gid) triple_map[tid_flat].resize(n_gid, kUnset);
-        if (triple_map[tid_smooth].size() < n_gid) triple_map[tid_smooth].resize(n_gid, kUnset);
-        map_flat = triple_map[tid_flat].data();
-        map_smooth = triple_map[tid_smooth].data();
-      }
       const size_t base = f.shapes.size();
       f.shapes.resize(base + gr.mtris.size());
       const Box mb = run.box;
       auto T0 = std::chrono::steady_clock::now();
-      for (size_t k = 0; k < gr.mtris.size(); k++) {
-        const uint32_t t = gr.mtris[k];
-        RtShape& r = f.shapes[base + k];
-        const bool smooth = m.smooth[t] == RTB_SMOOTH_TRIANGLE;
-        r.kind_flags = m.smooth[t] | RT_SHAPE_SHADOW;
-        r.xform = 0;
-        r.material = mat_index;
-        r.parent = (int32_t)idx;
-        uint32_t vc = RT_VCLASS_NEVER;
-        const uint32_t gid = m.gid[t];
-        if (map_flat && gid != RT_VCLASS_NEVER) {
-          uint32_t& slot = (smooth ? map_smooth : map_flat)[gid];
-          if (slot == kUnset) slot = shape_classes.fresh();
-          vc = slot;
-        }
-        r.vclass = vc;
-        r.prim = first_tri + (uint32_t)k;
-        r.mn = -kInf;
-        r.mx = kInf;
-      }
+      if (!inst) class_pass(m, gr.mtris, tid_flat, tid_smooth);
+      shape_fills.push_back(ShapeFill{base, gr.mesh, &gr.mtris, idx, first_tri, mat_index, tid_flat, tid_smooth});
       t_loop += std::chrono::duration<double>(std::chrono::steady_clock::now() - T0).count();
       box_merge(tb, mb);
       box_merge(bb, mb);
@@ -1248,17 +1500,28 @@ struct Flattener {
         n.idrun = 1 + (parent_node >= 0 ? f.nodes[parent_node].idrun : 0);
       }
     }
-    for (int c : gr.children) {
-      Box cb, ctb;
-      emit_group(c, (int)idx, &cb, &ctb);
-      if (gr.parent < 0) bb = box_transform(bb, gr.xf);
-      box_merge(bb, cb);
-      // child's true box, expressed in this node's space
-      const HGroup& cg = w.groups[c];
-      if (m4_is_identity(cg.xf))
-        box_merge(tb, ctb);
-      else
-        box_merge(tb, box_transform(ctb, cg.xf));
+    if (inst) {
+      auto T0 = std::chrono::steady_clock::now();
+      emit_instance_below(gr.mesh, *inst, *inst_flat, idx, first_shape, inst_created, mat_index, tid_flat, tid_smooth);
+      if (std::getenv("RT_TIMING")) std::fprintf(stderr, "flatten: instance nodes %.1f ms\n", 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - T0).count());
+      for (int k : inst->nodes[0].children) {
+        if (gr.parent < 0) bb = box_transform(bb, gr.xf);
+        box_merge(bb, inst_flat->box[k]);
+        box_merge(tb, inst_flat->box[k]);
+      }
+    } else {
+      for (int c : gr.children) {
+        Box cb, ctb;
+        emit_group(c, (int)idx, &cb, &ctb);
+        if (gr.parent < 0) bb = box_transform(bb, gr.xf);
+        box_merge(bb, cb);
+        // child's true box, expressed in this node's space
+        const HGroup& cg = w.groups[c];
+        if (m4_is_identity(cg.xf))
+          box_merge(tb, ctb);
+        else
+          box_merge(tb, box_transform(ctb, cg.xf));
+      }
     }
     if (gr.cached) bb = gr.bounds;  // cache_bounds() result taken at World-add time (scene.rs:197)
     RtNode& n = f.nodes[idx];
@@ -1280,6 +1543,7 @@ struct Flattener {
       size_t n_shapes = w.shapes.size(), n_nodes = w.groups.size();
       for (const HGroup& g : w.groups) n_shapes += g.mtris.size();
       f.shapes.reserve(n_shapes);
+      shape_classes.where.reserve(n_shapes);  // (at most one class a shape)
       f.nodes.reserve(n_nodes);
       true_box.reserve(n_nodes);
       size_t n_tris = w.tris.size();
@@ -1303,6 +1567,9 @@ struct Flattener {
     if (std::getenv("RT_TIMING")) std::fprintf(stderr, "flatten: groups %.3f s (triangle loops %.3f, geometry runs %.3f)\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - TG).count(), t_loop, t_run);
     uint32_t loose0 = (uint32_t)f.shapes.size();
     for (uint32_t s : w.world_shapes) emit_shape(s, -1);
+    auto TF = std::chrono::steady_clock::now();
+    run_fills();
+    if (std::getenv("RT_TIMING")) std::fprintf(stderr, "flatten: fills %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - TF).count());
     for (auto& l : w.lights) f.lights.push_back(l.l);
     RtScene& v = f.view;
     v = RtScene{};
@@ -1492,6 +1759,8 @@ int rth_group_new(RtbWorld* w, const RtbXfOp* ops, int nops) {
 int rth_group_set_transform(RtbWorld* w, int g, const RtbXfOp* ops, int nops) {
   if (g < 0 || g >= (int)w->groups.size()) return fail(w, "bad group handle");
   w->groups[g].xf = compose(ops, nops);
+  // (the instance root's own transform is its own business: what must stay as it is lies below it)
+  if (w->groups[g].parent >= 0) w->no_longer_template_copy(w->groups[g].parent);
   if (!m4_inverse(w->groups[g].xf, &w->groups[g].inv)) return fail(w, "group transform is not invertible");
   w->touch();
   return 0;
@@ -1510,6 +1779,7 @@ int rth_group_add_shape(RtbWorld* w, int g, int shape) {
 int rth_group_add_child(RtbWorld* w, int g, int child) {
   if (g < 0 || g >= (int)w->groups.size() || child < 0 || child >= (int)w->groups.size())
     return fail(w, "bad group handle");
+  if (w->groups[child].parent >= 0) w->no_longer_template_copy(w->groups[child].parent);
   w->attach_child(g, child);
   w->no_longer_template_bounds(g);
   w->touch();

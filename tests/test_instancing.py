@@ -25,7 +25,7 @@ def _relabel(a):
     return out
 
 
-def _world(pos, nrm, tris, smooth, thresholds, generic):
+def _world(pos, nrm, tris, smooth, thresholds, generic, after=None):
     w = host.new_world(0)
     for k, th in enumerate(thresholds):
         g = w.group([("rotate-y", 0.3 * k), ("translate", 3.0 * k, 0, 0)])
@@ -41,8 +41,10 @@ def _world(pos, nrm, tris, smooth, thresholds, generic):
                 w.group_add_shape(child, s)
             w.group_add_child(g, child)
         else:
-            w.group_add_mesh(g, mat, pos, nrm if smooth else None, tris, tris if smooth else None)
+            child = w.group_add_mesh(g, mat, pos, nrm if smooth else None, tris, tris if smooth else None)
         w.group_divide(g, th)
+        if after:
+            after(w, k, g, child)
         w.add_group(g)
     w.add_point_light((-5, 10, -5), (1, 1, 1))
     return abi.scene_arrays(w.flatten())
@@ -75,6 +77,50 @@ def test_mesh_path_flattens_like_one_shape_per_triangle():
             # one copy per distinct way of dividing the mesh at most (equal runs of different divisions are shared too)
             assert len(tris) <= len(a["tri_geom"]) <= len(tris) * len(set(thresholds))
             assert len(b["tri_geom"]) == len(tris) * len(thresholds)
+
+
+def _same_flatten(a, b):
+    assert len(a["nodes"]) == len(b["nodes"]) and len(a["shapes"]) == len(b["shapes"])
+    for f in ("bmin", "bmax", "xform", "flags", "first_shape", "n_shapes", "skip", "parent", "next_xf", "idrun", "n_children"):
+        assert a["nodes"][f].tobytes() == b["nodes"][f].tobytes(), f
+    for f in ("kind_flags", "xform", "material", "parent", "mn", "mx"):
+        assert a["shapes"][f].tobytes() == b["shapes"][f].tobytes(), f
+    assert np.array_equal(_relabel(a["shapes"]["vclass"]), _relabel(b["shapes"]["vclass"]))
+    tri = a["shapes"]["kind_flags"] & 0xF
+    tri = (tri == B.SHAPE_KINDS["triangle"]) | (tri == B.SHAPE_KINDS["smooth-triangle"])
+    assert tri.sum() >= len(a["shapes"]) - 3
+    assert np.array_equal(a["tri_geom"][a["shapes"]["prim"][tri]], b["tri_geom"][b["shapes"]["prim"][tri]])
+
+
+def test_copies_of_a_divide_template_that_are_changed_afterwards():
+    """An untouched copy of a divide template is flattened from the template; one that gets a shape, a child, a
+    transform or another divide afterwards must be walked group by group again -- and flatten like the generic path."""
+    rng = np.random.RandomState(11)
+    pos, nrm, tris = _mesh(rng, 10)
+
+    def divide_again(w, k, g, child):
+        if k != 1:
+            w.group_divide(g, 3)
+
+    def add_a_shape(w, k, g, child):
+        if k == 0:
+            w.group_add_shape(child, w.shape("sphere", [("scale", 0.2, 0.2, 0.2)], B.Material()))
+
+    def add_a_child(w, k, g, child):
+        if k == 2:
+            extra = w.group([("translate", 0, 1, 0)])
+            w.group_add_shape(extra, w.shape("cube", (), B.Material()))
+            w.group_add_child(child, extra)
+
+    def move_the_copy(w, k, g, child):
+        if k >= 1:
+            w.group_set_transform(child, [("scale", 1.0 + k, 1, 1)])
+
+    for after in (divide_again, add_a_shape, add_a_child, move_the_copy):
+        for smooth in (False, True):
+            a = _world(pos, nrm, tris, smooth, [8, 8, 8], generic=False, after=after)
+            b = _world(pos, nrm, tris, smooth, [8, 8, 8], generic=True, after=after)
+            _same_flatten(a, b)
 
 
 def test_six_dragons_hold_one_copy_of_the_triangles():
