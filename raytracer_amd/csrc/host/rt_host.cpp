@@ -309,6 +309,9 @@ struct HGroup {
   // this group is node 0 of an untouched copy of template `inst_tmpl`: every group below is what `instantiate` made
   // (nothing added, moved, divided again or given a transform since), so the flattener emits the subtree from the template
   int inst_tmpl = -1;
+  // ... and the groups below it have not been made at all (RtbWorld::realize makes them when anything needs them:
+  // nothing does when the copy goes to the flattener as it is)
+  bool lazy = false;
 };
 // The result of `divide` on a fresh mesh group (groups.rs:284-299), kept so that the next instance of the same mesh
 // with the same threshold is a copy of the tree instead of a second partition of 871 k triangles: the partition
@@ -652,7 +655,11 @@ struct RtbWorld {
   }
 
   // ---- groups (src/groups.rs) -----------------------------------------------------------
-  int group_len(int g) const { return (int)(groups[g].shapes.size() + groups[g].mtris.size() + groups[g].children.size()); }
+  int group_len(int g) const {
+    const HGroup& gr = groups[g];
+    const size_t kids = gr.lazy ? div_by_id[gr.inst_tmpl]->nodes[0].children.size() : gr.children.size();
+    return (int)(gr.shapes.size() + gr.mtris.size() + kids);
+  }
   // a mesh group's triangles as ordinary shapes (what the reference holds anyway), for the rare group that mixes a
   // mesh with other shapes; keeps the insertion order: the triangles came first
   void materialise(int g) {
@@ -694,6 +701,14 @@ struct RtbWorld {
     if (!gr.mtris.empty()) {
       const HMesh& m = *meshes[gr.mesh];
       for (uint32_t t : gr.mtris) box_merge(bb, m.box[t]);
+    }
+    if (gr.lazy) {  // (the children that realize() would make have parents: their bounds are their template nodes')
+      const DivTemplate& t = *div_by_id[gr.inst_tmpl];
+      for (int k : t.nodes[0].children) {
+        if (gr.parent < 0) bb = box_transform(bb, gr.xf);
+        box_merge(bb, t.nodes[k].sub);
+      }
+      return bb;
     }
     for (int c : gr.children) {
       if (gr.parent < 0) bb = box_transform(bb, gr.xf);  // the reference's root-with-children quirk
@@ -790,6 +805,21 @@ struct RtbWorld {
   // would make (a child is created, then everything below it): node k > 0 becomes group base + k - 1, and the copy is
   // one growth of the table and a fill in pieces on threads.
   void instantiate(int g, const DivTemplate& t) {
+    HGroup& root = groups[g];
+    root.mtris = t.nodes[0].mtris;
+    root.tmpl_id = t.id, root.tmpl_node = 0;
+    root.sub_id = t.id, root.sub_node = 0;
+    root.fresh_mesh = false;
+    root.inst_tmpl = t.id;
+    root.lazy = t.nodes.size() > 1;
+  }
+  // the groups below a lazy copy, made now (before anything that looks at them or changes the copy)
+  void realize(int g) {
+    if (!groups[g].lazy) return;
+    groups[g].lazy = false;
+    const DivTemplate& t = *div_by_id[groups[g].inst_tmpl];
+    if (groups.capacity() < groups.size() + t.nodes.size())  // one growth for the whole copy, with room for the next
+      groups.reserve(std::max(groups.capacity() * 2, groups.size() + 2 * t.nodes.size()));
     const size_t n = t.nodes.size();
     const int base = (int)groups.size();
     groups.resize(groups.size() + n - 1);
@@ -818,7 +848,6 @@ struct RtbWorld {
     for (size_t i = 1; i < nt; i++) th.emplace_back(fill, n * i / nt, n * (i + 1) / nt);
     fill(0, n / nt);
     for (auto& x : th) x.join();
-    groups[g].inst_tmpl = t.id;
   }
   // `divide` (groups.rs:284-299) of a group that holds only triangles `tris` of mesh `m`, as a template: partition if
   // threshold <= len (groups.rs:285), attach the non-empty halves, divide them.  Every group met on the way has no
@@ -896,12 +925,11 @@ struct RtbWorld {
         if (timing) std::fprintf(stderr, "divide: template of %zu groups %.1f ms\n", it->second.nodes.size(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
         t0 = std::chrono::steady_clock::now();
       }
-      if (groups.capacity() < groups.size() + it->second.nodes.size())  // one growth for the whole copy, with room for the next
-        groups.reserve(std::max(groups.capacity() * 2, groups.size() + 2 * it->second.nodes.size()));
       instantiate(g, it->second);
       if (timing) std::fprintf(stderr, "divide: instance %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
       return;
     }
+    realize(g);
     no_longer_template_copy(g);
     if (threshold <= group_len(g)) {
       int L, R;
@@ -1454,7 +1482,7 @@ struct Flattener {
     TmplFlat* inst_flat = nullptr;
     bool inst_created = false;
     if (gr.inst_tmpl >= 0 && gr.tmpl_id == gr.inst_tmpl && gr.tmpl_node == 0 && gr.shapes.empty() && gr.mesh >= 0 &&
-        gr.children.size() == w.div_by_id[gr.inst_tmpl]->nodes[0].children.size()) {
+        (gr.lazy || gr.children.size() == w.div_by_id[gr.inst_tmpl]->nodes[0].children.size())) {
       inst = w.div_by_id[gr.inst_tmpl];
       inst_created = tmpl_flat.find(gr.inst_tmpl) == tmpl_flat.end();
       inst_flat = &template_flat(gr.inst_tmpl, gr.mesh);
@@ -1491,7 +1519,7 @@ struct Flattener {
       n.n_shapes = n_shapes;
       n.parent = parent_node;
       n.first_tri = first_tri;
-      n.n_children = (uint32_t)gr.children.size();
+      n.n_children = (uint32_t)(inst ? inst->nodes[0].children.size() : gr.children.size());
       if (xf) {
         n.next_xf = (int32_t)idx;
         n.idrun = 0;
@@ -1540,8 +1568,22 @@ struct Flattener {
 
   void run() {
     {
+      // (a lazy copy is flattened from its template only as long as it is what instantiate() left: anything else
+      // gets its groups first -- no reference into w.groups is held yet)
+      for (size_t g = 0; g < w.groups.size(); g++) {
+        const HGroup& gr = w.groups[g];
+        if (gr.lazy && !(gr.inst_tmpl >= 0 && gr.tmpl_id == gr.inst_tmpl && gr.tmpl_node == 0 && gr.shapes.empty() && gr.mesh >= 0))
+          w.realize((int)g);
+      }
       size_t n_shapes = w.shapes.size(), n_nodes = w.groups.size();
-      for (const HGroup& g : w.groups) n_shapes += g.mtris.size();
+      for (const HGroup& g : w.groups) {
+        n_shapes += g.mtris.size();
+        if (g.lazy) {
+          const DivTemplate& t = *w.div_by_id[g.inst_tmpl];
+          n_nodes += t.nodes.size() - 1;
+          for (size_t k = 1; k < t.nodes.size(); k++) n_shapes += t.nodes[k].mtris.size();
+        }
+      }
       f.shapes.reserve(n_shapes);
       shape_classes.where.reserve(n_shapes);  // (at most one class a shape)
       f.nodes.reserve(n_nodes);
@@ -1768,6 +1810,7 @@ int rth_group_set_transform(RtbWorld* w, int g, const RtbXfOp* ops, int nops) {
 int rth_group_add_shape(RtbWorld* w, int g, int shape) {
   if (g < 0 || g >= (int)w->groups.size() || shape < 0 || shape >= (int)w->shapes.size())
     return fail(w, "bad handle");
+  w->realize(g);
   w->materialise(g);                             // a mesh group that also gets other shapes holds shapes only
   w->no_longer_template_bounds(g);
   uint32_t s = w->clone_shape((uint32_t)shape);  // groups.rs:80-85: the group owns a copy
@@ -1780,6 +1823,7 @@ int rth_group_add_child(RtbWorld* w, int g, int child) {
   if (g < 0 || g >= (int)w->groups.size() || child < 0 || child >= (int)w->groups.size())
     return fail(w, "bad group handle");
   if (w->groups[child].parent >= 0) w->no_longer_template_copy(w->groups[child].parent);
+  w->realize(g);
   w->attach_child(g, child);
   w->no_longer_template_bounds(g);
   w->touch();
@@ -1954,6 +1998,7 @@ int rth_group_add_mesh(RtbWorld* w, int g, const RtbMaterial* material, const fl
     w->meshes.push_back(std::move(mp));
     mesh = (int)w->meshes.size() - 1;
   }
+  w->realize(g);
   int child = w->new_group();
   HGroup& cg = w->groups[child];
   cg.mesh = mesh;

@@ -96,10 +96,31 @@ struct Tri {
   uint32_t kind_flags;
 };
 static_assert(sizeof(Tri) == 48, "aux triangle is 48 B");
+// resize() leaves new elements as they are: the leaf triangles are written in pieces on threads, and zeroing 42 MB of
+// them first on one thread took as long as writing them
+template <class T>
+struct RawAlloc : std::allocator<T> {
+  template <class U>
+  struct rebind {
+    typedef RawAlloc<U> other;
+  };
+  RawAlloc() = default;
+  template <class U>
+  RawAlloc(const RawAlloc<U>&) {}
+  template <class U>
+  void construct(U* p) {
+    ::new ((void*)p) U;
+  }
+  template <class U, class... A>
+  void construct(U* p, A&&... a) {
+    ::new ((void*)p) U(std::forward<A>(a)...);
+  }
+};
+typedef std::vector<Tri, RawAlloc<Tri>> TriVec;
 
 struct Result {
   std::vector<Node4> nodes;        // all trees back to back, and the entry records
-  std::vector<Tri> tris;           // leaf triangles in leaf order
+  TriVec tris;           // leaf triangles in leaf order
   std::vector<uint32_t> root_of;   // per reference node: header index of the subtree's BVH (roots only) or kNone
   std::vector<uint32_t> gate_next; // per reference node inside a subtree: next group whose box test is not implied
 };
@@ -118,7 +139,7 @@ struct TreeBuilder {
   const RtShape* shapes_ = nullptr;  // RtScene::shapes
   std::vector<Item> items;
   std::vector<Node> nodes;  // local; [0] header, [1] top
-  std::vector<Tri> tris;
+  TriVec tris;
   float lmax = 0.f, amax = 0.f;
   int depth_seen = 0;
   int par_levels = 0;  // top levels of the tree whose halves are built by separate threads (2^par_levels threads)
@@ -181,7 +202,7 @@ struct TreeBuilder {
   }
   struct Out {
     std::vector<Node> nodes;
-    std::vector<Tri> tris;
+    TriVec tris;
     int depth_seen = 0;
   };
   // child reference for [b,e): (index, count) and its box.  Nodes and leaf triangles go to `out` (indices local to it).
@@ -189,7 +210,7 @@ struct TreeBuilder {
   // then right -- the same pre-order layout as the serial build.
   void build(uint32_t b, uint32_t e, int depth, uint32_t* ref, uint32_t* count, float* lo, float* hi, Out& out, int par) {
     std::vector<Node>& nodes = out.nodes;
-    std::vector<Tri>& tris = out.tris;
+    TriVec& tris = out.tris;
     out.depth_seen = std::max(out.depth_seen, depth);
     for (int a = 0; a < 3; a++) lo[a] = INFINITY, hi[a] = -INFINITY;
     for (uint32_t i = b; i < e; i++)
@@ -482,38 +503,30 @@ inline Result build(const RtScene* s, const DeviceTree& device_tree = nullptr) {
       for (uint32_t k = 0; k < n.n_shapes; k++) f(n.first_tri + k, n.first_shape + k, i);
     }
   };
-  // canonical triangle ids: the smallest index with the same 48 bytes of geometry, so that instances are recognised
-  // whether the host shares one copy of the triangles between them (this repo's flattener) or repeats them (a host
-  // that flattens the reference's duplicated World as it is)
-  std::vector<uint32_t> canon(s->n_tris);
-  {
-    size_t cap = 16;
-    while (cap < (size_t)s->n_tris * 2 + 16) cap <<= 1;
-    std::vector<uint32_t> slots(cap, kNone);
-    for (uint32_t t = 0; t < s->n_tris; t++) {
-      uint64_t h = 1469598103934665603ull;
-      uint64_t w[6];
-      std::memcpy(w, &s->tri_geom[t], 48);
-      for (uint64_t x : w) {
-        h = (h ^ x) * 0x100000001B3ull;
-        h ^= h >> 29;
-      }
-      size_t i = h & (cap - 1);
-      while (slots[i] != kNone && std::memcmp(&s->tri_geom[slots[i]], &s->tri_geom[t], 48) != 0) i = (i + 1) & (cap - 1);
-      if (slots[i] == kNone) slots[i] = t;
-      canon[t] = slots[i];
-    }
-  }
-  stage("roots, canonical triangles");
+  // Two subtrees are the same instance when their items agree one by one: the triangle (see below), the shape index
+  // relative to the instance's first shape, the owning group relative to the root, the kind and flags.  "The same
+  // triangle" is decided in two rounds.  First by index: this repo's flattener shares one copy of the triangle data
+  // between the instances of a mesh, so equal indices settle it for them (dragons.yaml: five of six roots) without
+  // looking at a triangle.  Roots still on their own after that are compared by CANONICAL triangle ids -- the
+  // smallest index with the same 48 bytes of geometry -- so that instances are also recognised for a host that
+  // flattens the reference's duplicated World as it is (one hash table over all triangles, built only then).
   std::vector<Inst> inst(roots.size());
-  auto hash_root = [&](size_t j) {
+  for (size_t j = 0; j < roots.size(); j++) {
     Inst& I = inst[j];
     I.same_as = j;
     I.shape_base = 0xFFFFFFFFu;
-    for_items(roots[j], [&](uint32_t, uint32_t shape, uint32_t) { I.shape_base = std::min(I.shape_base, shape), I.n_items++; });
+    for (uint32_t i = roots[j]; i < s->nodes[roots[j]].skip; i++) {
+      const RtNode& n = s->nodes[i];
+      if (n.n_shapes == 0) continue;
+      I.n_items += n.n_shapes;
+      I.shape_base = std::min(I.shape_base, n.first_shape);
+    }
+  }
+  auto hash_root = [&](size_t j, const uint32_t* canon) {
+    Inst& I = inst[j];
     uint64_t h = 1469598103934665603ull;
     for_items(roots[j], [&](uint32_t tri, uint32_t shape, uint32_t owner) {
-      const uint64_t a = ((uint64_t)canon[tri] << 32) | (shape - I.shape_base);
+      const uint64_t a = ((uint64_t)(canon ? canon[tri] : tri) << 32) | (shape - I.shape_base);
       const uint64_t b = ((uint64_t)(owner - roots[j]) << 32) | s->shapes[shape].kind_flags;
       h = (h ^ a) * 0x100000001B3ull;
       h ^= h >> 29;
@@ -522,43 +535,101 @@ inline Result build(const RtScene* s, const DeviceTree& device_tree = nullptr) {
     });
     I.hash = h;
   };
-  {  // (one root per thread: six dragons are 5.2 M items)
-    const unsigned nt_h = roots.size() >= 2 ? std::max(1u, std::min<unsigned>(8u, std::min<unsigned>((unsigned)roots.size(), std::thread::hardware_concurrency()))) : 1u;
-    std::vector<std::thread> pool;
-    for (unsigned t = 1; t < nt_h; t++)
-      pool.emplace_back([&, t] {
-        for (size_t j = t; j < roots.size(); j += nt_h) hash_root(j);
-      });
-    for (size_t j = 0; j < roots.size(); j += nt_h) hash_root(j);
-    for (auto& th : pool) th.join();
-  }
-  auto same_items = [&](size_t j1, size_t j2) {  // full comparison behind a hash match
+  // item by item, two cursors (groups without shapes of their own do not count)
+  auto same_items = [&](size_t j1, size_t j2, const uint32_t* canon) {
     if (inst[j1].n_items != inst[j2].n_items) return false;
-    std::vector<uint32_t> t1;
-    t1.reserve((size_t)inst[j1].n_items * 4);
-    for_items(roots[j1], [&](uint32_t tri, uint32_t shape, uint32_t owner) {
-      t1.push_back(canon[tri]), t1.push_back(shape - inst[j1].shape_base), t1.push_back(owner - roots[j1]),
-          t1.push_back(s->shapes[shape].kind_flags);
-    });
-    size_t q = 0;
-    bool same = true;
-    for_items(roots[j2], [&](uint32_t tri, uint32_t shape, uint32_t owner) {
-      same = same && t1[q] == canon[tri] && t1[q + 1] == shape - inst[j2].shape_base && t1[q + 2] == owner - roots[j2] &&
-             t1[q + 3] == s->shapes[shape].kind_flags;
-      q += 4;
-    });
-    return same;
-  };
-  for (size_t j = 1; j < roots.size(); j++)
-    for (size_t q = 0; q < j; q++)
-      if (inst[q].same_as == q && inst[q].hash == inst[j].hash && same_items(q, j)) {
-        inst[j].same_as = q;
-        break;
+    const uint32_t R1 = roots[j1], R2 = roots[j2], E2 = s->nodes[R2].skip;
+    uint32_t i2 = R2, k2 = 0;
+    for (uint32_t i1 = R1; i1 < s->nodes[R1].skip; i1++) {
+      const RtNode& a = s->nodes[i1];
+      for (uint32_t k1 = 0; k1 < a.n_shapes; k1++) {
+        while (i2 < E2 && k2 >= s->nodes[i2].n_shapes) i2++, k2 = 0;
+        if (i2 >= E2) return false;
+        const RtNode& b = s->nodes[i2];
+        const uint32_t t1 = a.first_tri + k1, t2 = b.first_tri + k2, s1 = a.first_shape + k1, s2 = b.first_shape + k2;
+        if ((canon ? canon[t1] != canon[t2] : t1 != t2) || s1 - inst[j1].shape_base != s2 - inst[j2].shape_base ||
+            i1 - R1 != i2 - R2 || s->shapes[s1].kind_flags != s->shapes[s2].kind_flags)
+          return false;
+        k2++;
       }
+    }
+    return true;
+  };
+  // one root per thread (six dragons are 5.2 M items): hash, then compare with the first root of the same hash; what
+  // that leaves undecided (a root that differs from the first of its hash) is settled in order afterwards
+  auto round = [&](const std::vector<size_t>& which, const uint32_t* canon) {
+    const unsigned nt_h = which.size() >= 2 ? std::max(1u, std::min<unsigned>(8u, std::min<unsigned>((unsigned)which.size(), std::thread::hardware_concurrency()))) : 1u;
+    auto on_threads = [&](auto&& f) {
+      std::vector<std::thread> pool;
+      for (unsigned t = 1; t < nt_h; t++)
+        pool.emplace_back([&, t] {
+          for (size_t q = t; q < which.size(); q += nt_h) f(q);
+        });
+      for (size_t q = 0; q < which.size(); q += nt_h) f(q);
+      for (auto& th : pool) th.join();
+    };
+    on_threads([&](size_t q) { hash_root(which[q], canon); });
+    std::vector<int> first_same(which.size(), -1);  // position in `which` of the first root with this hash, if it is the same
+    std::vector<uint8_t> undecided(which.size(), 0);
+    on_threads([&](size_t q) {
+      for (size_t p = 0; p < q; p++)
+        if (inst[which[p]].hash == inst[which[q]].hash) {
+          if (same_items(which[p], which[q], canon))
+            first_same[q] = (int)p;
+          else
+            undecided[q] = 1;
+          return;
+        }
+    });
+    for (size_t q = 0; q < which.size(); q++) {
+      const size_t j = which[q];
+      if (first_same[q] >= 0) {
+        inst[j].same_as = inst[which[(size_t)first_same[q]]].same_as;  // (the first of a hash is settled before its followers)
+      } else if (undecided[q]) {
+        for (size_t p = 0; p < q; p++)
+          if (inst[which[p]].same_as == which[p] && inst[which[p]].hash == inst[j].hash && same_items(which[p], j, canon)) {
+            inst[j].same_as = which[p];
+            break;
+          }
+      }
+    }
+  };
+  {
+    std::vector<size_t> all(roots.size());
+    for (size_t j = 0; j < roots.size(); j++) all[j] = j;
+    round(all, nullptr);
+  }
+  stage("roots, instances by index");
+  {
+    std::vector<size_t> alone;
+    for (size_t j = 0; j < roots.size(); j++)
+      if (inst[j].same_as == j) alone.push_back(j);
+    if (alone.size() >= 2) {
+      std::vector<uint32_t> canon(s->n_tris);
+      size_t cap = 16;
+      while (cap < (size_t)s->n_tris * 2 + 16) cap <<= 1;
+      std::vector<uint32_t> slots(cap, kNone);
+      for (uint32_t t = 0; t < s->n_tris; t++) {
+        uint64_t h = 1469598103934665603ull;
+        uint64_t w[6];
+        std::memcpy(w, &s->tri_geom[t], 48);
+        for (uint64_t x : w) {
+          h = (h ^ x) * 0x100000001B3ull;
+          h ^= h >> 29;
+        }
+        size_t i = h & (cap - 1);
+        while (slots[i] != kNone && std::memcmp(&s->tri_geom[slots[i]], &s->tri_geom[t], 48) != 0) i = (i + 1) & (cap - 1);
+        if (slots[i] == kNone) slots[i] = t;
+        canon[t] = slots[i];
+      }
+      round(alone, canon.data());
+      for (size_t j = 0; j < roots.size(); j++) inst[j].same_as = inst[inst[j].same_as].same_as;  // followers of a root that has just found its own
+    }
+  }
   stage("instances");
   struct Out {
     std::vector<Node> nodes;
-    std::vector<Tri> tris;
+    TriVec tris;
     bool ok = false;
     uint32_t top = 0;  // index of the top node in Result::nodes
   };
@@ -657,10 +728,30 @@ inline Result build(const RtScene* s, const DeviceTree& device_tree = nullptr) {
       }
     } fold{bn, r.nodes, tbase};
     fold.emit(1);
-    for (Tri t : outs[j].tris) {
-      t.shape -= inst[j].shape_base;
-      t.owner -= roots[j];
-      r.tris.push_back(t);
+    {  // leaf triangles: relative to the instance, in pieces on threads (871 k of them for a dragon)
+      TriVec& src = outs[j].tris;
+      const uint32_t sb = inst[j].shape_base, rb = roots[j];
+      const size_t n = src.size();
+      const unsigned ntc = n >= (1u << 16) ? std::max(1u, std::min(8u, std::thread::hardware_concurrency())) : 1u;
+      const bool moved = r.tris.empty();
+      if (moved)
+        r.tris = std::move(src);
+      else
+        r.tris.resize(tbase + n);
+      Tri* dst = r.tris.data() + tbase;
+      const Tri* from = moved ? dst : src.data();
+      auto piece = [&](unsigned t) {
+        for (size_t k = n * t / ntc; k < n * (t + 1) / ntc; k++) {
+          Tri x = from[k];
+          x.shape -= sb;
+          x.owner -= rb;
+          dst[k] = x;
+        }
+      };
+      std::vector<std::thread> pool;
+      for (unsigned t = 1; t < ntc; t++) pool.emplace_back(piece, t);
+      piece(0);
+      for (auto& th : pool) th.join();
     }
   }
   stage("fold to 4-wide nodes, leaves");

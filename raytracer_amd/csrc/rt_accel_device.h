@@ -58,7 +58,7 @@ struct Glob {
   uint32_t bad;        // a non-finite triangle: the subtree keeps the reference walk (TreeBuilder::add)
   uint32_t n_nodes;    // binary nodes allocated (0 = header, 1 = top)
   uint32_t n_next;     // nodes of the next level
-  uint32_t give_up;    // (unused: nothing makes the device give a tree up any more; kept for the layout)
+  uint32_t max_next;   // triangles of the largest node of the next level (k_children)
   uint32_t n_median;   // nodes of this level that take the object-median split, up to kMedianMax triangles (k_median)
   uint32_t n_large;    // ... and larger ones (k_mcount / k_mupdate)
 };
@@ -103,7 +103,7 @@ __global__ void k_init(uint32_t n, uint32_t* perm, uint32_t* node_of, WNode* wn,
     wnode_init(wn[0], 0, n, kNoW, 0);
     for (int a = 0; a < 3; a++) g->blo[a] = f2o(INFINITY), g->bhi[a] = f2o(-INFINITY);
     g->lmax = g->amax = f2o(0.f);
-    g->bad = 0, g->n_nodes = 1, g->n_next = 0, g->give_up = 0, g->n_median = 0, g->n_large = 0;
+    g->bad = 0, g->n_nodes = 1, g->n_next = 0, g->max_next = 0, g->n_median = 0, g->n_large = 0;
   }
 }
 
@@ -190,55 +190,102 @@ __device__ __forceinline__ bool run_head(const uint32_t key) {
   return key != kNoW && (lane == 0u || prev != key);
 }
 
-__global__ void k_bounds(const uint32_t* perm, const uint32_t* node_of, const float* f, uint32_t n, WNode* wn) {
-  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t key = p < n ? node_of[p] : kNoW;
-  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}, c[3] = {0.f, 0.f, 0.f};
-  long long ax[3] = {0, 0, 0};
-  float kmax = 0.f;
-  int bad = 0;
-  if (key != kNoW) {
-    const uint32_t it = perm[p];
-    for (int a = 0; a < 3; a++) {
-      lo[a] = f[(size_t)a * n + it];
-      hi[a] = f[(size_t)(3 + a) * n + it];
-      c[a] = f[(size_t)(6 + a) * n + it];
-      ax[a] = llrint((double)f[(size_t)(9 + a) * n + it] * 4294967296.0);
-    }
-    const float ka = f[(size_t)12 * n + it];
-    bad = !isfinite(ka);
-    kmax = bad ? 0.f : ka;
+// A block takes kBoundsChunks consecutive pieces of 256 positions.  What belongs to the node of the block's first
+// position is gathered in LDS and goes to memory once a block (high in the tree every position of a block belongs to
+// one node, and one atomic per run of a wave was 218 k atomics on sixteen words: 3.9 of the level's 4 ms); runs of
+// other nodes go to memory directly, as before.
+constexpr uint32_t kBoundsChunks = 4;
+__global__ __launch_bounds__(256) void k_bounds(const uint32_t* perm, const uint32_t* node_of, const float* f, uint32_t n, WNode* wn) {
+  __shared__ int Llo[3], Lhi[3], Lclo[3], Lchi[3], Lkmax;
+  __shared__ unsigned long long Lax[3];
+  __shared__ uint32_t Lbad, Lany, ukey;
+  const uint32_t p_first = blockIdx.x * (kBoundsChunks * 256u);
+  if (threadIdx.x == 0) {
+    ukey = p_first < n ? node_of[p_first] : kNoW;
+    Lbad = 0u, Lany = 0u, Lkmax = f2o(-INFINITY);
+    for (int a = 0; a < 3; a++) Llo[a] = Lclo[a] = f2o(INFINITY), Lhi[a] = Lchi[a] = f2o(-INFINITY), Lax[a] = 0ull;
   }
+  __syncthreads();
   auto fmin_ = [](float x, float y) { return fminf(x, y); };
   auto fmax_ = [](float x, float y) { return fmaxf(x, y); };
   auto add_ = [](long long x, long long y) { return x + y; };
   auto or_ = [](int x, int y) { return x | y; };
-  float clo[3], chi[3];
-  for (int a = 0; a < 3; a++) {
-    clo[a] = run_reduce(c[a], key, fmin_);
-    chi[a] = run_reduce(c[a], key, fmax_);
-    lo[a] = run_reduce(lo[a], key, fmin_);
-    hi[a] = run_reduce(hi[a], key, fmax_);
-    ax[a] = run_reduce(ax[a], key, add_);
-  }
-  kmax = run_reduce(kmax, key, fmax_);
-  bad = run_reduce(bad, key, or_);
-  if (run_head(key)) {
-    WNode& w = wn[key];
-    for (int a = 0; a < 3; a++) {
-      atomicMin(&w.lo[a], f2o(lo[a]));
-      atomicMax(&w.hi[a], f2o(hi[a]));
-      atomicMin(&w.clo[a], f2o(clo[a]));
-      atomicMax(&w.chi[a], f2o(chi[a]));
-      atomicAdd(reinterpret_cast<unsigned long long*>(&w.ax[a]), (unsigned long long)ax[a]);
+  for (uint32_t ch = 0; ch < kBoundsChunks; ch++) {
+    const uint32_t p = p_first + ch * 256u + threadIdx.x;
+    const uint32_t key = p < n ? node_of[p] : kNoW;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}, c[3] = {0.f, 0.f, 0.f};
+    long long ax[3] = {0, 0, 0};
+    float kmax = 0.f;
+    int bad = 0;
+    if (key != kNoW) {
+      const uint32_t it = perm[p];
+      for (int a = 0; a < 3; a++) {
+        lo[a] = f[(size_t)a * n + it];
+        hi[a] = f[(size_t)(3 + a) * n + it];
+        c[a] = f[(size_t)(6 + a) * n + it];
+        ax[a] = llrint((double)f[(size_t)(9 + a) * n + it] * 4294967296.0);
+      }
+      const float ka = f[(size_t)12 * n + it];
+      bad = !isfinite(ka);
+      kmax = bad ? 0.f : ka;
     }
-    atomicMax(&w.kmax, f2o(kmax));
-    if (bad) atomicOr(&w.bad, 1u);
+    float clo[3], chi[3];
+    for (int a = 0; a < 3; a++) {
+      clo[a] = run_reduce(c[a], key, fmin_);
+      chi[a] = run_reduce(c[a], key, fmax_);
+      lo[a] = run_reduce(lo[a], key, fmin_);
+      hi[a] = run_reduce(hi[a], key, fmax_);
+      ax[a] = run_reduce(ax[a], key, add_);
+    }
+    kmax = run_reduce(kmax, key, fmax_);
+    bad = run_reduce(bad, key, or_);
+    if (run_head(key)) {
+      if (key == ukey) {
+        for (int a = 0; a < 3; a++) {
+          atomicMin(&Llo[a], f2o(lo[a]));
+          atomicMax(&Lhi[a], f2o(hi[a]));
+          atomicMin(&Lclo[a], f2o(clo[a]));
+          atomicMax(&Lchi[a], f2o(chi[a]));
+          atomicAdd(&Lax[a], (unsigned long long)ax[a]);
+        }
+        atomicMax(&Lkmax, f2o(kmax));
+        if (bad) atomicOr(&Lbad, 1u);
+        Lany = 1u;
+      } else {
+        WNode& w = wn[key];
+        for (int a = 0; a < 3; a++) {
+          atomicMin(&w.lo[a], f2o(lo[a]));
+          atomicMax(&w.hi[a], f2o(hi[a]));
+          atomicMin(&w.clo[a], f2o(clo[a]));
+          atomicMax(&w.chi[a], f2o(chi[a]));
+          atomicAdd(reinterpret_cast<unsigned long long*>(&w.ax[a]), (unsigned long long)ax[a]);
+        }
+        atomicMax(&w.kmax, f2o(kmax));
+        if (bad) atomicOr(&w.bad, 1u);
+      }
+    }
+  }
+  __syncthreads();
+  if (Lany && ukey != kNoW) {
+    WNode& w = wn[ukey];
+    const uint32_t a = threadIdx.x;
+    if (a < 3u) {
+      atomicMin(&w.lo[a], Llo[a]);
+      atomicMax(&w.hi[a], Lhi[a]);
+      atomicMin(&w.clo[a], Lclo[a]);
+      atomicMax(&w.chi[a], Lchi[a]);
+      atomicAdd(reinterpret_cast<unsigned long long*>(&w.ax[a]), Lax[a]);
+    }
+    if (a == 3u) {
+      atomicMax(&w.kmax, Lkmax);
+      if (Lbad) atomicOr(&w.bad, 1u);
+    }
   }
 }
 
-__global__ void k_prep(WNode* wn, uint32_t m, Bin* bins) {
+__global__ void k_prep(WNode* wn, uint32_t m, Bin* bins, Glob* g) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0u) g->n_next = 0u, g->n_median = 0u, g->n_large = 0u, g->max_next = 0u;  // this level's counters (the host has read the last level's)
   if (i >= m) return;
   WNode& w = wn[i];
   const uint32_t n = w.e - w.b;
@@ -273,15 +320,17 @@ __device__ __forceinline__ int bin_of(float c, float lo_c, float scale) {
   return min(kBins - 1, max(0, (int)((c - lo_c) * scale)));
 }
 
+constexpr uint32_t kBinChunks = 1;  // pieces of 256 positions a block takes (4: one flush of LDS bins instead of four high in the tree,
+                                    // but four times as many levels whose nodes are narrower than a block and bin straight to memory: 7.4 -> 11.4 ms)
 __global__ __launch_bounds__(256) void k_bin(const uint32_t* perm, const uint32_t* node_of, const float* f, uint32_t n, WNode* wn,
                                              Bin* bins) {
   __shared__ Bin L[3 * kBins];
   __shared__ uint32_t ukey;  // the block's one node, or kNoW when its positions belong to several (or to none)
-  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t key = p < n ? node_of[p] : kNoW;
+  const uint32_t p_first = blockIdx.x * (kBinChunks * 256u);
   if (threadIdx.x == 0) {
-    const uint32_t last = min(n, (blockIdx.x + 1u) * blockDim.x) - 1u;
-    ukey = node_of[last] == key ? key : kNoW;
+    const uint32_t last = min(n, p_first + kBinChunks * 256u) - 1u;
+    const uint32_t k0 = p_first < n ? node_of[p_first] : kNoW;
+    ukey = (k0 != kNoW && node_of[last] == k0) ? k0 : kNoW;
   }
   for (uint32_t k = threadIdx.x; k < 3 * kBins; k += blockDim.x) {
     L[k].cnt = 0;
@@ -289,42 +338,46 @@ __global__ __launch_bounds__(256) void k_bin(const uint32_t* perm, const uint32_
   }
   __syncthreads();
   const bool in_lds = ukey != kNoW;
-  bool active = false;
-  double cosv = 1.0;
-  if (key != kNoW) {
-    const WNode& w = wn[key];
-    if (w.e - w.b > rtaccel::kLeafTris) {
-      active = true;
-      const uint32_t it = perm[p];
-      int lo[3], hi[3];
-      float c[3], nr[3];
-      for (int a = 0; a < 3; a++) {
-        lo[a] = f2o(f[(size_t)a * n + it]);
-        hi[a] = f2o(f[(size_t)(3 + a) * n + it]);
-        c[a] = f[(size_t)(6 + a) * n + it];
-        nr[a] = f[(size_t)(9 + a) * n + it];
-      }
-      for (int axis = 0; axis < 3; axis++) {
-        if (!((w.axis_ok >> axis) & 1u)) continue;
-        const int k = bin_of(c[axis], w.lo_c[axis], w.scale[axis]);
-        if (in_lds) {
-          Bin& B = L[axis * kBins + k];
-          atomicAdd(&B.cnt, 1u);
-          for (int a = 0; a < 3; a++) atomicMin(&B.lo[a], lo[a]), atomicMax(&B.hi[a], hi[a]);
-        } else {
-          Bin& B = bins[((size_t)key * 3 + axis) * kBins + k];
-          atomicAdd(&B.cnt, 1u);
-          for (int a = 0; a < 3; a++) atomicMin(&B.lo[a], lo[a]), atomicMax(&B.hi[a], hi[a]);
+  for (uint32_t ch = 0; ch < kBinChunks; ch++) {
+    const uint32_t p = p_first + ch * 256u + threadIdx.x;
+    const uint32_t key = p < n ? node_of[p] : kNoW;
+    bool active = false;
+    double cosv = 1.0;
+    if (key != kNoW) {
+      const WNode& w = wn[key];
+      if (w.e - w.b > rtaccel::kLeafTris) {
+        active = true;
+        const uint32_t it = perm[p];
+        int lo[3], hi[3];
+        float c[3], nr[3];
+        for (int a = 0; a < 3; a++) {
+          lo[a] = f2o(f[(size_t)a * n + it]);
+          hi[a] = f2o(f[(size_t)(3 + a) * n + it]);
+          c[a] = f[(size_t)(6 + a) * n + it];
+          nr[a] = f[(size_t)(9 + a) * n + it];
         }
+        for (int axis = 0; axis < 3; axis++) {
+          if (!((w.axis_ok >> axis) & 1u)) continue;
+          const int k = bin_of(c[axis], w.lo_c[axis], w.scale[axis]);
+          if (in_lds) {
+            Bin& B = L[axis * kBins + k];
+            atomicAdd(&B.cnt, 1u);
+            for (int a = 0; a < 3; a++) atomicMin(&B.lo[a], lo[a]), atomicMax(&B.hi[a], hi[a]);
+          } else {
+            Bin& B = bins[((size_t)key * 3 + axis) * kBins + k];
+            atomicAdd(&B.cnt, 1u);
+            for (int a = 0; a < 3; a++) atomicMin(&B.lo[a], lo[a]), atomicMax(&B.hi[a], hi[a]);
+          }
+        }
+        if (w.cone_ok) cosv = (w.axd[0] * nr[0] + w.axd[1] * nr[1] + w.axd[2] * nr[2]) / w.al;
       }
-      if (w.cone_ok) cosv = (w.axd[0] * nr[0] + w.axd[1] * nr[1] + w.axd[2] * nr[2]) / w.al;
     }
-  }
-  // smallest cosine of the node: runs of the wave, one atomic each
-  {
-    const uint32_t k2 = active ? key : kNoW;
-    const double mn = run_reduce(cosv, k2, [](double x, double y) { return x < y ? x : y; });
-    if (run_head(k2) && wn[k2].cone_ok) atomicMin(&wn[k2].cmin, d2o(mn));
+    // smallest cosine of the node: runs of the wave, one atomic each
+    {
+      const uint32_t k2 = active ? key : kNoW;
+      const double mn = run_reduce(cosv, k2, [](double x, double y) { return x < y ? x : y; });
+      if (run_head(k2) && wn[k2].cone_ok) atomicMin(&wn[k2].cmin, d2o(mn));
+    }
   }
   __syncthreads();
   if (in_lds)
@@ -560,6 +613,7 @@ __global__ void k_children(WNode* wn, uint32_t m, WNode* next, const uint32_t* p
   const uint32_t n_left = prefix_at(pre, block_sum, w.e - 1u) + flag[w.e - 1u] - prefix_at(pre, block_sum, w.b);
   const uint32_t mid = w.b + n_left;
   const uint32_t s = atomicAdd(&g->n_next, 2u);
+  atomicMax(&g->max_next, max(n_left, (w.e - w.b) - n_left));
   w.child0 = s;
   wnode_init(next[s], w.b, mid, w.me, 0);
   wnode_init(next[s + 1], mid, w.e, w.me, 1);
@@ -621,6 +675,15 @@ inline bool build_tree(int device, const RtScene* s, uint32_t R, rtaccel::TreeBu
     t_prev = now;
   };
   if (hipSetDevice(device) != hipSuccess) return false;
+  // the per-level counters come back through page-locked memory (two read-backs a level: into pageable memory each
+  // one went through a staging copy); freed after the stream has drained
+  struct Pinned {
+    Glob* p = nullptr;
+    ~Pinned() {
+      if (p) (void)hipHostFree(p);
+    }
+  } pinned;
+  if (hipHostMalloc(reinterpret_cast<void**>(&pinned.p), sizeof(Glob), hipHostMallocDefault) != hipSuccess) return false;
   hipStream_t st = nullptr;
   if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return false;
   struct StreamGuard {
@@ -661,26 +724,31 @@ inline bool build_tree(int device, const RtScene* s, uint32_t R, rtaccel::TreeBu
   if (!d_w.ensure(w_cap) || !d_w2.ensure(2 * w_cap) || !d_bins.ensure(w_cap * 3 * kBins) || !d_mlist.ensure(w_cap)) return false;
   hipLaunchKernelGGL(k_init, dim3(nb), dim3(256), 0, st, n, d_perm.p, d_node.p, d_w.p, d_g.p);
   hipLaunchKernelGGL(k_items, dim3(nb), dim3(256), 0, st, d_geom.p, d_tri.p, n, d_f.p, d_g.p);
-  Glob g{};
-  uint32_t m = 1;
+  Glob& g = *pinned.p;
+  g = Glob{};
+  uint32_t m = 1, level_max = n;
   int depth = 1, depth_seen = 1;
   while (m > 0) {
     depth_seen = depth;
     const uint32_t mb = (m + 63u) / 64u;
-    hipLaunchKernelGGL(k_bounds, dim3(nb), dim3(256), 0, st, d_perm.p, d_node.p, d_f.p, n, d_w.p);
-    hipLaunchKernelGGL(k_prep, dim3(mb), dim3(64), 0, st, d_w.p, m, d_bins.p);
-    hipLaunchKernelGGL(k_bin, dim3(nb), dim3(256), 0, st, d_perm.p, d_node.p, d_f.p, n, d_w.p, d_bins.p);
+    hipLaunchKernelGGL(k_bounds, dim3((nb + kBoundsChunks - 1u) / kBoundsChunks), dim3(256), 0, st, d_perm.p, d_node.p, d_f.p, n, d_w.p);
+    hipLaunchKernelGGL(k_prep, dim3(mb), dim3(64), 0, st, d_w.p, m, d_bins.p, d_g.p);
+    hipLaunchKernelGGL(k_bin, dim3((nb + kBinChunks - 1u) / kBinChunks), dim3(256), 0, st, d_perm.p, d_node.p, d_f.p, n, d_w.p, d_bins.p);
     hipLaunchKernelGGL(k_split, dim3(mb), dim3(64), 0, st, d_w.p, m, d_bins.p, d_nodes.p, d_g.p, depth, d_mlist.p);
-    RT_DEV_TRY(hipMemcpyAsync(&g, d_g.p, sizeof(g), hipMemcpyDeviceToHost, st));
-    RT_DEV_TRY(hipStreamSynchronize(st));
-    if (g.n_large)  // object-median splits of large nodes (deep under a mesh close to what one tree can hold)
-      for (int round = 0; round < 64; round++) {
-        hipLaunchKernelGGL(k_mcount, dim3(nb), dim3(256), 0, st, d_perm.p, d_node.p, d_f.p, d_shape.p, n, d_w.p);
-        hipLaunchKernelGGL(k_mupdate, dim3(mb), dim3(64), 0, st, d_w.p, m);
-      }
-    if (g.n_median)
-      hipLaunchKernelGGL(k_median, dim3(std::min<uint32_t>(g.n_median, 2048u)), dim3(256), 0, st, d_perm.p, d_f.p, d_shape.p, n, d_w.p,
-                         d_mlist.p, d_g.p, d_mflag.p);
+    // object-median splits of large nodes (deep under a mesh close to what one tree can hold): the host has to know of
+    // them, which costs a round trip -- only on levels that still have a node that large
+    if (level_max > kMedianMax) {
+      RT_DEV_TRY(hipMemcpyAsync(&g, d_g.p, sizeof(g), hipMemcpyDeviceToHost, st));
+      RT_DEV_TRY(hipStreamSynchronize(st));
+      if (g.n_large)
+        for (int round = 0; round < 64; round++) {
+          hipLaunchKernelGGL(k_mcount, dim3(nb), dim3(256), 0, st, d_perm.p, d_node.p, d_f.p, d_shape.p, n, d_w.p);
+          hipLaunchKernelGGL(k_mupdate, dim3(mb), dim3(64), 0, st, d_w.p, m);
+        }
+    }
+    // (its blocks take the entries of the list the device counted: any grid will do)
+    hipLaunchKernelGGL(k_median, dim3(std::min<uint32_t>(m, 2048u)), dim3(256), 0, st, d_perm.p, d_f.p, d_shape.p, n, d_w.p, d_mlist.p,
+                       d_g.p, d_mflag.p);
     hipLaunchKernelGGL(k_flags, dim3(nb), dim3(256), 0, st, d_perm.p, d_node.p, d_f.p, d_shape.p, n, d_w.p, d_mflag.p, d_pre.p,
                        d_flag.p, d_bsum.p);
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, d_bsum.p, nb);
@@ -690,10 +758,11 @@ inline bool build_tree(int device, const RtScene* s, uint32_t R, rtaccel::TreeBu
     RT_DEV_TRY(hipGetLastError());
     RT_DEV_TRY(hipMemcpyAsync(&g, d_g.p, sizeof(g), hipMemcpyDeviceToHost, st));
     RT_DEV_TRY(hipStreamSynchronize(st));
-    if (g.bad || g.give_up) {
-      if (timing) std::fprintf(stderr, "device tree: declined at depth %d (%s)\n", depth, g.bad ? "non-finite triangle" : "gave up");
+    if (g.bad) {
+      if (timing) std::fprintf(stderr, "device tree: declined at depth %d (non-finite triangle)\n", depth);
       return false;
     }
+    level_max = g.max_next;
     std::swap(d_perm.p, d_perm2.p);
     std::swap(d_node.p, d_node2.p);
     m = g.n_next;
@@ -710,8 +779,6 @@ inline bool build_tree(int device, const RtScene* s, uint32_t R, rtaccel::TreeBu
       if (!d_bins.ensure((size_t)2 * m * 3 * kBins)) return false;
     }
     if (d_mlist.cap < (size_t)m && !d_mlist.ensure(2 * (size_t)m)) return false;
-    RT_DEV_TRY(hipMemsetAsync(&d_g.p->n_next, 0, sizeof(uint32_t), st));
-    RT_DEV_TRY(hipMemsetAsync(&d_g.p->n_median, 0, 2 * sizeof(uint32_t), st));  // n_median, n_large
   }
   stage("levels");
   const uint32_t n_nodes = g.n_nodes;
@@ -722,6 +789,40 @@ inline bool build_tree(int device, const RtScene* s, uint32_t R, rtaccel::TreeBu
   RT_DEV_TRY(hipMemcpyAsync(perm.data(), d_perm.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
   RT_DEV_TRY(hipStreamSynchronize(st));
 #undef RT_DEV_TRY
+  // the leaf triangles need the permutation only: gathered on threads while this one renumbers the nodes
+  tb.tris.resize(n);
+  std::vector<std::thread> th;
+  {
+    auto fill = [&, t_lo](uint32_t p0, uint32_t p1) {
+      for (uint32_t p = p0; p < p1; p++) {
+        const uint32_t it = perm[p];
+        const RtTriGeom& q = s->tri_geom[tri[it] + t_lo];
+        rtaccel::Tri t{};
+        std::memcpy(t.p1, q.p1, 12);
+        std::memcpy(t.e1, q.e1, 12);
+        std::memcpy(t.e2, q.e2, 12);
+        t.shape = shape[it];
+        t.owner = owner[it];
+        t.kind_flags = s->shapes[shape[it]].kind_flags;
+        tb.tris[p] = t;
+      }
+    };
+    const uint32_t nt = n >= (1u << 16) ? std::max(1u, std::min(8u, std::thread::hardware_concurrency())) : 1u;
+    for (uint32_t k = 0; k < nt; k++) {
+      const uint32_t p0 = (uint32_t)((uint64_t)n * k / nt), p1 = (uint32_t)((uint64_t)n * (k + 1) / nt);
+      if (nt == 1)
+        fill(p0, p1);
+      else
+        th.emplace_back(fill, p0, p1);
+    }
+  }
+  struct Joiner {
+    std::vector<std::thread>& th;
+    ~Joiner() {
+      for (auto& t : th)
+        if (t.joinable()) t.join();
+    }
+  } joiner{th};
   // pre-order numbering (TreeBuilder's layout: a node, its left subtree, its right subtree)
   std::vector<uint32_t> new_of(n_nodes, 0);
   {
@@ -744,28 +845,7 @@ inline bool build_tree(int device, const RtScene* s, uint32_t R, rtaccel::TreeBu
     if (nd.rcount == 0) nd.right = new_of[nd.right];
     tb.nodes[new_of[q]] = nd;
   }
-  tb.tris.resize(n);
-  {
-    auto fill = [&](uint32_t p0, uint32_t p1) {
-      for (uint32_t p = p0; p < p1; p++) {
-        const uint32_t it = perm[p];
-        const RtTriGeom& q = s->tri_geom[tri[it] + t_lo];
-        rtaccel::Tri t{};
-        std::memcpy(t.p1, q.p1, 12);
-        std::memcpy(t.e1, q.e1, 12);
-        std::memcpy(t.e2, q.e2, 12);
-        t.shape = shape[it];
-        t.owner = owner[it];
-        t.kind_flags = s->shapes[shape[it]].kind_flags;
-        tb.tris[p] = t;
-      }
-    };
-    const uint32_t nt = n >= (1u << 16) ? std::max(1u, std::min(8u, std::thread::hardware_concurrency())) : 1u;
-    std::vector<std::thread> th;
-    for (uint32_t k = 1; k < nt; k++) th.emplace_back(fill, (uint32_t)((uint64_t)n * k / nt), (uint32_t)((uint64_t)n * (k + 1) / nt));
-    fill(0, (uint32_t)((uint64_t)n / nt));
-    for (auto& t : th) t.join();
-  }
+  for (auto& t : th) t.join();
   stage("download, pre-order, leaf triangles");
   tb.depth_seen = depth_seen;
   if (depth_seen > rtaccel::kMaxDepth) return false;

@@ -123,6 +123,39 @@ def test_copies_of_a_divide_template_that_are_changed_afterwards():
             _same_flatten(a, b)
 
 
+def _tops(w):
+    acc = abi.accel_arrays(host.hip_lib(), w.flatten())
+    heads = acc["root_of"][acc["root_of"] != 0xFFFFFFFF]
+    return [int(acc["nodes"]["b"][h]["v"][1][2:3].copy().view("<u4")[0]) for h in heads]
+
+
+def test_instances_share_a_tree_whoever_flattened_them():
+    """rt_accel_build recognises instances by triangle index when the host shares one copy of the triangle data
+    (this repo's flattener) and by the triangles' bytes when it repeats them (a flatten of the reference's World, which
+    re-parses the OBJ file per instance): one auxiliary tree per distinct division either way."""
+    rng = np.random.RandomState(5)
+    pos, nrm, tris = _mesh(rng, 9)
+    for generic in (False, True):
+        for thresholds, n_trees in (([6, 6, 6], 1), ([6, 9, 6, 9], 2), ([4, 5, 6], 3)):
+            w = host.new_world(0)
+            for k, th in enumerate(thresholds):
+                g = w.group([("translate", 3.0 * k, 0, 0)])
+                mat = B.Material(color=(1.0, 0.1 * k, 0.2))
+                if generic:
+                    child = w.group(())
+                    for t in tris:
+                        w.group_add_shape(child, w.shape("triangle", (), mat, params=[*pos[t[0]], *pos[t[1]], *pos[t[2]]]))
+                    w.group_add_child(g, child)
+                else:
+                    w.group_add_mesh(g, mat, pos, None, tris, None)
+                w.group_divide(g, th)
+                w.add_group(g)
+            w.add_point_light((-5, 10, -5), (1, 1, 1))
+            tops = _tops(w)
+            assert len(tops) == len(thresholds) and len(set(tops)) == n_trees, (generic, thresholds, tops)
+            assert tops[0] == min(tops) and all(tops[k] == tops[thresholds.index(th)] for k, th in enumerate(thresholds))
+
+
 def test_six_dragons_hold_one_copy_of_the_triangles():
     scene = small_dragons(24, 16)
     fs = scene.build(host.new_world(0)).flatten()
