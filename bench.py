@@ -285,7 +285,15 @@ def main():
     host_frame_u8_ms = None
     host_pinned_ms = None
     eighths_ms = None
+    setup_again_s = None
     if world == 1 and rank == 0 and not args.no_extras:
+        # the same world built and uploaded a second time: set-up without what a process pays once (HIP start-up, the
+        # context, the code object)
+        t0 = time.time()
+        hw2 = scene.build(host.new_world(local_rank))
+        hw2.device_scene()
+        setup_again_s = round(time.time() - t0, 3)
+        del hw2
         hbuf = np.empty((cam.vsize, cam.hsize, 3), dtype=np.float32)
         fopts = abi.RtRenderOptions(abi.RT_JITTER_COUNTER, 0.5, 1, 1, 1, 0, 0)
         hms = []
@@ -426,7 +434,7 @@ def main():
                        "frame_ms": round(ms_per_step, 3), "host_frame_ms": host_frame_ms, "host_frame_u8_ms": host_frame_u8_ms,
                        "host_frame_pinned_ms": host_pinned_ms[0] if host_pinned_ms else None,
                        "host_frame_u8_pinned_ms": host_pinned_ms[1] if host_pinned_ms else None,
-                       "eighths_kernel_ms": eighths_ms, "scene_setup_s": round(setup_s, 2),
+                       "eighths_kernel_ms": eighths_ms, "scene_setup_s": round(setup_s, 2), "scene_setup_again_s": setup_again_s,
                        "other_workloads": other},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }

@@ -258,6 +258,27 @@ struct HPattern {
   int uv_mapping = 0;
   int uv[6] = {-1, -1, -1, -1, -1, -1};
 };
+// resize() of the big arrays leaves new elements of trivial types as they are (every one is written afterwards, in
+// pieces on threads): zeroing 5 M shape records on one thread first was a sixth of the flatten, 871 k triangles of a
+// mesh two thirds of making them
+template <class T>
+struct RawAlloc : std::allocator<T> {
+  template <class U>
+  struct rebind {
+    typedef RawAlloc<U> other;
+  };
+  RawAlloc() = default;
+  template <class U>
+  RawAlloc(const RawAlloc<U>&) {}
+  template <class U>
+  void construct(U* p) {
+    ::new ((void*)p) U;
+  }
+  template <class U, class... A>
+  void construct(U* p, A&&... a) {
+    ::new ((void*)p) U(std::forward<A>(a)...);
+  }
+};
 struct HTri {
   P3 p1, p2, p3, e1, e2;
   P3 n1, n2, n3;  // flat: n1 = normal
@@ -270,7 +291,7 @@ struct HMesh {
   uint64_t hash = 0;               // of the inputs, to recognise the same mesh handed in again
   std::vector<float> in_pos, in_nrm;
   std::vector<int32_t> in_vidx, in_nidx;
-  std::vector<HTri> tris;
+  std::vector<HTri, RawAlloc<HTri>> tris;
   std::vector<uint8_t> smooth;     // RTB_SMOOTH_TRIANGLE or RTB_TRIANGLE per triangle (obj.rs:24-36)
   std::vector<Box> box;            // parent_space_bounds of each triangle (identity transform, shapes.rs:318-320)
   std::vector<uint32_t> gid;       // value class of the triangle's geometry (TriValueTable), RT_VCLASS_NEVER if it holds a NaN
@@ -508,28 +529,94 @@ struct TriValueTable {
     slots[i] = (uint32_t)rep.size();
     return (uint32_t)rep.size() - 1;
   }
+  // The classes of a whole mesh at once, on threads: the ids get_hashed() would give triangle after triangle (a value
+  // seen before keeps its id, new values are numbered in the order of their first triangles).  Every triangle finds
+  // the slot of its value in the open-addressed table, claiming an empty one with a compare-and-swap; a claimed slot
+  // holds the SMALLEST index of the triangles with that value (0x80000000 | index until the ids are known), so that
+  // the numbering does not depend on who came first.  Slots only ever go from empty to taken, and triangles of one
+  // value probe the same sequence: two of them cannot end up in two slots.
+  static bool same_value(const HTri& a, const HTri& b, bool smooth) {
+    uint32_t wa[25], wb[25];
+    int na, nb;
+    bool nan;
+    words(a, smooth, wa, &na, &nan);
+    words(b, smooth, wb, &nb, &nan);
+    return std::memcmp(wa, wb, 4 * (size_t)na) == 0;
+  }
+  template <class Tris>
+  void get_batch(const Tris& tris, const uint8_t* kind, const uint64_t* hs, const uint8_t* nans, uint32_t n, uint32_t* gid, unsigned nt) {
+    reserve(n);
+    const size_t mask = slots.size() - 1;
+    uint32_t* S = slots.data();
+    std::vector<uint32_t> slot_of(n), new_id(n, 0);
+    auto on_threads = [&](auto&& f) {
+      std::vector<std::thread> pool;
+      for (unsigned k = 1; k < nt; k++) pool.emplace_back([&, k] { f((uint32_t)((uint64_t)n * k / nt), (uint32_t)((uint64_t)n * (k + 1) / nt)); });
+      f(0u, (uint32_t)((uint64_t)n / nt));
+      for (auto& th : pool) th.join();
+    };
+    on_threads([&](uint32_t b, uint32_t e) {
+      for (uint32_t t = b; t < e; t++) {
+        if (nans[t]) continue;
+        const bool smooth = kind[t] == RTB_SMOOTH_TRIANGLE;
+        const uint32_t mine = 0x80000000u | t;
+        size_t i = hs[t] & mask;
+        while (true) {
+          uint32_t v = __atomic_load_n(&S[i], __ATOMIC_ACQUIRE);
+          if (v == 0u) {
+            if (__atomic_compare_exchange_n(&S[i], &v, mine, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE)) break;
+            // (v now holds what another thread put there)
+          }
+          bool same;
+          if (v & 0x80000000u) {
+            const uint32_t o = v & 0x7FFFFFFFu;
+            same = hs[o] == hs[t] && (kind[o] == RTB_SMOOTH_TRIANGLE) == smooth && same_value(tris[t], tris[o], smooth);
+          } else {
+            const uint32_t id = v - 1u;
+            same = rep_hash[id] == hs[t] && (rep_smooth[id] != 0) == smooth && same_value(tris[t], *rep[id], smooth);
+          }
+          if (same) {
+            while ((v & 0x80000000u) && mine < v && !__atomic_compare_exchange_n(&S[i], &v, mine, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE)) {
+            }
+            break;
+          }
+          i = (i + 1) & mask;
+        }
+        slot_of[t] = (uint32_t)i;
+      }
+    });
+    // the first triangle of every new value, in order: its id
+    uint32_t next = (uint32_t)rep.size();
+    for (uint32_t t = 0; t < n; t++)
+      if (!nans[t] && S[slot_of[t]] == (0x80000000u | t)) new_id[t] = next++;
+    const uint32_t first_new = (uint32_t)rep.size();
+    rep.resize(next);
+    rep_smooth.resize(next);
+    rep_hash.resize(next);
+    on_threads([&](uint32_t b, uint32_t e) {
+      for (uint32_t t = b; t < e; t++) {
+        if (nans[t]) {
+          gid[t] = RT_VCLASS_NEVER;
+          continue;
+        }
+        const uint32_t v = S[slot_of[t]];
+        if (v & 0x80000000u) {
+          const uint32_t o = v & 0x7FFFFFFFu;
+          gid[t] = new_id[o];
+          if (o == t) rep[new_id[t]] = &tris[t], rep_smooth[new_id[t]] = kind[t] == RTB_SMOOTH_TRIANGLE, rep_hash[new_id[t]] = hs[t];
+        } else {
+          gid[t] = v - 1u;
+        }
+      }
+    });
+    on_threads([&](uint32_t b, uint32_t e) {  // (after everybody has read the provisional entries)
+      for (uint32_t t = b; t < e; t++)
+        if (!nans[t] && S[slot_of[t]] == (0x80000000u | t)) S[slot_of[t]] = new_id[t] + 1u;
+    });
+    (void)first_new;
+  }
 };
 
-// resize() of the big arrays leaves the new elements as they are (every one is written by the fills of the flattener,
-// in pieces on threads): zeroing 5 M shape records first was a sixth of the flatten
-template <class T>
-struct RawAlloc : std::allocator<T> {
-  template <class U>
-  struct rebind {
-    typedef RawAlloc<U> other;
-  };
-  RawAlloc() = default;
-  template <class U>
-  RawAlloc(const RawAlloc<U>&) {}
-  template <class U>
-  void construct(U* p) {
-    ::new ((void*)p) U;
-  }
-  template <class U, class... A>
-  void construct(U* p, A&&... a) {
-    ::new ((void*)p) U(std::forward<A>(a)...);
-  }
-};
 struct Flat {
   std::vector<RtXform> xforms;
   std::vector<RtShape, RawAlloc<RtShape>> shapes;
@@ -1991,8 +2078,7 @@ int rth_group_add_mesh(RtbWorld* w, int g, const RtbMaterial* material, const fl
         for (int k = 0; k < n_threads; k++) pool.emplace_back(hash_work, std::min(ntriangles, k * per), std::min(ntriangles, (k + 1) * per));
         for (auto& th : pool) th.join();
       }
-      for (int t = 0; t < ntriangles; t++)
-        m.gid[t] = w->tri_values.get_hashed(m.tris[t], m.smooth[t] == RTB_SMOOTH_TRIANGLE, hs[t], nans[t] != 0);
+      w->tri_values.get_batch(m.tris, m.smooth.data(), hs.data(), nans.data(), (uint32_t)ntriangles, m.gid.data(), (unsigned)n_threads);
     }
     stage("geometry value classes");
     w->meshes.push_back(std::move(mp));

@@ -156,6 +156,45 @@ def test_instances_share_a_tree_whoever_flattened_them():
             assert tops[0] == min(tops) and all(tops[k] == tops[thresholds.index(th)] for k, th in enumerate(thresholds))
 
 
+def test_value_classes_of_a_big_mesh_with_repeated_triangles():
+    """Meshes of 65 536 triangles and more get their geometry classes on threads (TriValueTable::get_batch): the same
+    equalities as the one-shape-per-triangle path finds, with every third triangle a repeat of an earlier one, some
+    of them listed with -0 for 0, and a triangle holding a NaN (equal to nothing, not even itself)."""
+    rng = np.random.RandomState(21)
+    n = 66_000
+    base = rng.randint(-50, 50, size=(n, 3, 3)).astype(np.float32)
+    rep = rng.randint(0, n // 2, size=n // 3)
+    base[n - len(rep):] = base[rep]
+    base[base == 0][::2] *= -1.0
+    zeros = np.flatnonzero((base == 0).any(axis=(1, 2)))[:500]
+    base[zeros] = np.where(base[zeros] == 0, np.float32(-0.0), base[zeros])
+    base[1234, 1, 2] = np.nan
+    base[n - 7] = base[1234]
+    pos = base.reshape(-1, 3)
+    tris = np.arange(3 * n, dtype=np.int32).reshape(n, 3)
+    mat = B.Material(color=(0.3, 0.4, 0.5))
+
+    def classes(generic):
+        w = host.new_world(0)
+        g = w.group(())
+        if generic:
+            child = w.group(())
+            for t in tris:
+                w.group_add_shape(child, w.shape("triangle", (), mat, params=[*pos[t[0]], *pos[t[1]], *pos[t[2]]]))
+            w.group_add_child(g, child)
+        else:
+            w.group_add_mesh(g, mat, pos, None, tris, None)
+        w.add_group(g)
+        w.add_point_light((-5, 10, -5), (1, 1, 1))
+        return abi.scene_arrays(w.flatten())["shapes"]["vclass"].copy()
+
+    a, b = classes(False), classes(True)
+    never = 0xFFFFFFFF
+    assert a[1234] == never and a[n - 7] == never and np.array_equal(a == never, b == never)
+    assert np.array_equal(_relabel(a), _relabel(b))
+    assert len(set(a.tolist())) < n - len(rep) + 2
+
+
 def test_six_dragons_hold_one_copy_of_the_triangles():
     scene = small_dragons(24, 16)
     fs = scene.build(host.new_world(0)).flatten()
