@@ -341,6 +341,7 @@ struct DivNode {
   std::vector<uint32_t> mtris;
   std::vector<int> children;  // indices into DivTemplate::nodes
   Box sub;                    // union of the boxes of every triangle at or below the node
+  Box own;                    // ... of the node's own triangles (mtris), merged in their order
 };
 struct DivTemplate {
   std::vector<DivNode> nodes;  // [0] = the mesh group itself
@@ -394,8 +395,12 @@ struct KeyBuilder {
 // spent ~10 s on the 5.2 M triangles of dragons.yaml).
 struct ClassTable {
   std::vector<char> arena;
-  std::vector<uint64_t> where;  // per id: offset << 16 | length
-  std::vector<uint32_t> slots;  // id + 1, 0 = empty
+  struct Keyed {
+    uint64_t where;  // offset << 16 | length of the key in the arena
+    uint32_t id;
+  };
+  std::vector<Keyed> keyed;     // the classes that have a key (fresh() hands out ids without one: millions of them for a mesh)
+  std::vector<uint32_t> slots;  // index into keyed + 1, 0 = empty
   uint32_t next = 0;
   static uint64_t hash(const char* p, uint32_t n) {
     uint64_t h = 0x9E3779B97F4A7C15ull;
@@ -410,37 +415,32 @@ struct ClassTable {
   void grow() {
     size_t cap = slots.empty() ? 1024 : slots.size() * 2;
     std::vector<uint32_t> ns(cap, 0);
-    for (uint32_t id = 0; id < next; id++) {
-      uint64_t w = where[id];
-      if ((w & 0xFFFF) == 0) continue;  // an id handed out by fresh(): it has no key
+    for (uint32_t q = 0; q < keyed.size(); q++) {
+      const uint64_t w = keyed[q].where;
       size_t i = hash(arena.data() + (w >> 16), (uint32_t)(w & 0xFFFF)) & (cap - 1);
       while (ns[i]) i = (i + 1) & (cap - 1);
-      ns[i] = id + 1;
+      ns[i] = q + 1;
     }
     slots.swap(ns);
   }
-  uint32_t fresh() {  // a new class id that no key maps to (the caller keeps its own index to it)
-    where.push_back(0);
-    return next++;
-  }
-  uint32_t fresh_n(uint32_t n) {  // n of them in a row; returns the first
-    where.insert(where.end(), n, 0);
+  uint32_t fresh() { return next++; }  // a new class id that no key maps to (the caller keeps its own index to it)
+  uint32_t fresh_n(uint32_t n) {       // n of them in a row; returns the first
     next += n;
     return next - n;
   }
   uint32_t get(const KeyBuilder& k) {
     if (k.nan) return RT_VCLASS_NEVER;
-    if ((size_t)(next + 1) * 2 > slots.size()) grow();
+    if ((keyed.size() + 1) * 2 > slots.size()) grow();
     const size_t mask = slots.size() - 1;
     size_t i = hash(k.bytes, k.len) & mask;
     while (slots[i]) {
-      uint64_t w = where[slots[i] - 1];
-      if ((w & 0xFFFF) == k.len && std::memcmp(arena.data() + (w >> 16), k.bytes, k.len) == 0) return slots[i] - 1;
+      const Keyed& e = keyed[slots[i] - 1];
+      if ((e.where & 0xFFFF) == k.len && std::memcmp(arena.data() + (e.where >> 16), k.bytes, k.len) == 0) return e.id;
       i = (i + 1) & mask;
     }
-    where.push_back(((uint64_t)arena.size() << 16) | k.len);
+    keyed.push_back(Keyed{((uint64_t)arena.size() << 16) | k.len, next});
     arena.insert(arena.end(), k.bytes, k.bytes + k.len);
-    slots[i] = next + 1;
+    slots[i] = (uint32_t)keyed.size();
     return next++;
   }
 };
@@ -992,6 +992,11 @@ struct RtbWorld {
         }
       }
     }
+    {
+      Box own;
+      for (uint32_t q : tris) box_merge(own, m.box[q]);
+      t.nodes[me].own = own;
+    }
     t.nodes[me].mtris = std::move(tris);
   }
   void divide(int g, int threshold) {  // :284-299
@@ -1053,6 +1058,26 @@ struct Flattener {
   ClassTable triple_classes;
   std::vector<std::vector<uint32_t>> triple_map;
   std::vector<size_t> triple_set;  // per triple: how many entries of its map hold a class
+  // A triple whose classes so far are those of ONE untouched template copy met while its table was empty: class of
+  // geometry g = base + rank[g] (TmplFlat::rank_*), and no table is made for it -- unless somebody else turns up with the
+  // same triple (map_of).
+  struct TripleLazy {
+    const uint32_t* rank = nullptr;
+    uint32_t base = 0;
+  };
+  std::vector<TripleLazy> triple_lazy;
+  uint32_t* map_of(uint32_t tid) {
+    std::vector<uint32_t>& mp = triple_map[tid];
+    const size_t n_gid = w.tri_values.rep.size();
+    if (mp.size() < n_gid) mp.resize(n_gid, kUnset);
+    if (triple_lazy[tid].rank) {
+      const TripleLazy tl = triple_lazy[tid];
+      triple_lazy[tid] = TripleLazy{};
+      for (size_t g = 0; g < n_gid; g++)
+        if (tl.rank[g] != kUnset) mp[g] = tl.base + tl.rank[g];
+    }
+    return mp.data();
+  }
   static constexpr uint32_t kUnset = 0xFFFFFFFEu;
   // Triangle data already emitted, by (mesh, sequence of triangle indices): instances of one mesh, divided the same
   // way, share their tri_geom / tri_normals entries (a node's own triangles are a contiguous run of them).
@@ -1087,8 +1112,15 @@ struct Flattener {
   void fill_shapes(const ShapeFill& sf) {
     const std::vector<uint32_t>& mtris = *sf.mtris;
     const HMesh& m = *w.meshes[sf.mesh];
-    const uint32_t* map_flat = sf.tid_flat != RT_VCLASS_NEVER ? triple_map[sf.tid_flat].data() : nullptr;
-    const uint32_t* map_smooth = sf.tid_flat != RT_VCLASS_NEVER ? triple_map[sf.tid_smooth].data() : nullptr;
+    // (run_fills: nothing changes the tables any more -- a triple is still lazy or has its table)
+    const uint32_t* map_flat = nullptr;
+    const uint32_t* map_smooth = nullptr;
+    uint32_t add_flat = 0, add_smooth = 0;
+    if (sf.tid_flat != RT_VCLASS_NEVER) {
+      const TripleLazy &lf = triple_lazy[sf.tid_flat], &ls = triple_lazy[sf.tid_smooth];
+      map_flat = lf.rank ? lf.rank : triple_map[sf.tid_flat].data(), add_flat = lf.rank ? lf.base : 0u;
+      map_smooth = ls.rank ? ls.rank : triple_map[sf.tid_smooth].data(), add_smooth = ls.rank ? ls.base : 0u;
+    }
     for (size_t k = 0; k < mtris.size(); k++) {
       const uint32_t t = mtris[k];
       RtShape r{};
@@ -1097,7 +1129,8 @@ struct Flattener {
       r.material = sf.mat_index;
       r.parent = (int32_t)sf.node;
       const uint32_t gid = m.gid[t];
-      r.vclass = (map_flat && gid != RT_VCLASS_NEVER) ? (m.smooth[t] == RTB_SMOOTH_TRIANGLE ? map_smooth : map_flat)[gid] : RT_VCLASS_NEVER;
+      const bool smooth = m.smooth[t] == RTB_SMOOTH_TRIANGLE;
+      r.vclass = (map_flat && gid != RT_VCLASS_NEVER) ? (smooth ? map_smooth : map_flat)[gid] + (smooth ? add_smooth : add_flat) : RT_VCLASS_NEVER;
       r.prim = sf.first_tri + (uint32_t)k;
       r.mn = -kInf;
       r.mx = kInf;
@@ -1137,13 +1170,12 @@ struct Flattener {
     KeyBuilder k;
     k.u(kind), k.fs(xf.a, 16), k.u(mclass), k.u(shadow ? 1 : 0);
     const uint32_t tid = triple_classes.get(k);
-    if (tid != RT_VCLASS_NEVER && tid >= triple_map.size()) triple_map.resize(tid + 1), triple_set.resize(tid + 1, 0);
+    if (tid != RT_VCLASS_NEVER && tid >= triple_map.size()) triple_map.resize(tid + 1), triple_set.resize(tid + 1, 0), triple_lazy.resize(tid + 1);
     return tid;
   }
   uint32_t tri_vclass(uint32_t tid, uint32_t gid) {
     if (tid == RT_VCLASS_NEVER || gid == RT_VCLASS_NEVER) return RT_VCLASS_NEVER;
-    std::vector<uint32_t>& mp = triple_map[tid];
-    if (gid >= mp.size()) mp.resize(std::max<size_t>(gid + 1, w.tri_values.rep.size()), kUnset);
+    uint32_t* mp = map_of(tid);
     if (mp[gid] == kUnset) mp[gid] = shape_classes.fresh(), triple_set[tid]++;
     return mp[gid];
   }
@@ -1167,8 +1199,9 @@ struct Flattener {
     std::vector<uint32_t> prefix;       // triangles of the nodes before k in pre-order
     std::vector<Box> box;               // merge of the node's run box and its children's boxes, in that order
     std::vector<uint32_t> flags;
-    // distinct (geometry class, smooth) of the whole template in the order a walk first meets them (bit 31: smooth)
-    std::vector<uint32_t> first_met;
+    // the distinct (geometry class, smooth) of the whole template numbered in the order a walk first meets them
+    std::vector<uint32_t> rank_flat, rank_smooth;  // per geometry class, kUnset: not in the template
+    uint32_t n_first_met = 0, n_flat = 0, n_smooth = 0;
     bool first_met_done = false;
   };
   std::unordered_map<int, TmplFlat> tmpl_flat;
@@ -1177,6 +1210,7 @@ struct Flattener {
     if (it != tmpl_flat.end()) return it->second;
     const DivTemplate& t = *w.div_by_id[tmpl_id];
     const size_t n = t.nodes.size();
+    const auto T0 = std::chrono::steady_clock::now();
     TmplFlat tf;
     tf.run.reserve(n);
     tf.size_before.resize(n);
@@ -1188,10 +1222,15 @@ struct Flattener {
     tf.flags.resize(n);
     for (size_t k = 0; k < n; k++) {
       tf.size_before[k] = (uint32_t)f.tri_geom.size();
-      if (t.nodes[k].mtris.empty())
-        tf.run.push_back(Run{mesh, &t.nodes[k].mtris, tf.size_before[k], Box{}});
-      else
-        tf.run.push_back(geometry_run(mesh, t.nodes[k].mtris, -1, -1));
+      // (the node's triangle data goes behind what is there: template runs are not looked up among the runs of
+      // other groups, nor entered there)
+      const size_t cnt = t.nodes[k].mtris.size();
+      if (cnt) {
+        f.tri_geom.resize(tf.size_before[k] + cnt);
+        f.tri_normals.resize(tf.size_before[k] + cnt);
+        tri_fills.push_back(TriFill{tf.size_before[k], mesh, &t.nodes[k].mtris});
+      }
+      tf.run.push_back(Run{mesh, &t.nodes[k].mtris, tf.size_before[k], cnt ? t.nodes[k].own : Box{}});
       tf.prefix[k + 1] = tf.prefix[k] + (uint32_t)t.nodes[k].mtris.size();
       for (int c : t.nodes[k].children) tf.parent[c] = (int)k, tf.depth[c] = tf.depth[k] + 1;
     }
@@ -1207,6 +1246,7 @@ struct Flattener {
       const bool empty = bb.lo.x > bb.hi.x && bb.lo.y > bb.hi.y && bb.lo.z > bb.hi.z;
       tf.flags[k] = (!nd.mtris.empty() ? RT_NODE_ALL_TRIS : 0u) | ((encloses || empty) ? RT_NODE_PRUNABLE : 0u);
     }
+    if (std::getenv("RT_TIMING")) std::fprintf(stderr, "flatten: template of %zu nodes prepared in %.1f ms\n", n, 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - T0).count());
     return tmpl_flat.emplace(tmpl_id, std::move(tf)).first->second;
   }
   const Run& geometry_run(int mesh, const std::vector<uint32_t>& seq, int tmpl_id, int tmpl_node) {
@@ -1448,18 +1488,13 @@ struct Flattener {
                                                          triple_id(RTB_SMOOTH_TRIANGLE, ident, mclass, true))).first;
     }
     *tid_flat = tids->second.first, *tid_smooth = tids->second.second;
-    const size_t n_gid = w.tri_values.rep.size();
-    if (*tid_flat != RT_VCLASS_NEVER) {
-      if (triple_map[*tid_flat].size() < n_gid) triple_map[*tid_flat].resize(n_gid, kUnset);
-      if (triple_map[*tid_smooth].size() < n_gid) triple_map[*tid_smooth].resize(n_gid, kUnset);
-    }
   }
   // value classes of a run of mesh triangles, in the order the shapes are met (the numbering is part of the output);
   // the records themselves are written later (fill_shapes)
   void class_pass(const HMesh& m, const std::vector<uint32_t>& mtris, uint32_t tid_flat, uint32_t tid_smooth) {
     if (tid_flat == RT_VCLASS_NEVER) return;
-    uint32_t* map_flat = triple_map[tid_flat].data();
-    uint32_t* map_smooth = triple_map[tid_smooth].data();
+    uint32_t* map_flat = map_of(tid_flat);
+    uint32_t* map_smooth = map_of(tid_smooth);
     for (size_t k = 0; k < mtris.size(); k++) {
       const uint32_t t = mtris[k];
       const uint32_t gid = m.gid[t];
@@ -1485,28 +1520,26 @@ struct Flattener {
       return;
     }
     if (!tf.first_met_done) {
-      std::vector<uint8_t> seen(w.tri_values.rep.size(), 0);  // bit 0: as a flat triangle, bit 1: as a smooth one
+      const size_t n_gid = w.tri_values.rep.size();
+      tf.rank_flat.assign(n_gid, kUnset);
+      tf.rank_smooth.assign(n_gid, kUnset);
       for (const DivNode& nd : t.nodes)
         for (uint32_t q : nd.mtris) {
           const uint32_t gid = m.gid[q];
           if (gid == RT_VCLASS_NEVER) continue;
           const bool smooth = m.smooth[q] == RTB_SMOOTH_TRIANGLE;
-          const uint8_t bit = smooth ? 2 : 1;
-          if (seen[gid] & bit) continue;
-          seen[gid] |= bit;
-          tf.first_met.push_back(gid | (smooth ? 0x80000000u : 0u));
+          uint32_t& r = (smooth ? tf.rank_smooth : tf.rank_flat)[gid];
+          if (r != kUnset) continue;
+          r = tf.n_first_met++;
+          (smooth ? tf.n_smooth : tf.n_flat)++;
         }
       tf.first_met_done = true;
     }
-    uint32_t* map_flat = triple_map[tid_flat].data();
-    uint32_t* map_smooth = triple_map[tid_smooth].data();
-    const uint32_t base = shape_classes.fresh_n((uint32_t)tf.first_met.size());
-    for (size_t i = 0; i < tf.first_met.size(); i++) {
-      const uint32_t e = tf.first_met[i];
-      const bool smooth = (e & 0x80000000u) != 0u;
-      (smooth ? map_smooth : map_flat)[e & 0x7FFFFFFFu] = base + (uint32_t)i;
-      triple_set[smooth ? tid_smooth : tid_flat]++;
-    }
+    const uint32_t base = shape_classes.fresh_n(tf.n_first_met);
+    triple_lazy[tid_flat] = TripleLazy{tf.rank_flat.data(), base};
+    triple_lazy[tid_smooth] = TripleLazy{tf.rank_smooth.data(), base};
+    triple_set[tid_flat] += tf.n_flat;
+    triple_set[tid_smooth] += tf.n_smooth;
   }
   // The groups below the root of an untouched template copy (HGroup::inst_tmpl): node k of the template is node
   // idx + k here, its shapes follow the root's by prefix[k]; everything else a walk would have found out about it is
@@ -1672,7 +1705,6 @@ struct Flattener {
         }
       }
       f.shapes.reserve(n_shapes);
-      shape_classes.where.reserve(n_shapes);  // (at most one class a shape)
       f.nodes.reserve(n_nodes);
       true_box.reserve(n_nodes);
       size_t n_tris = w.tris.size();
