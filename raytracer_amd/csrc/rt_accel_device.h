@@ -604,8 +604,8 @@ __global__ __launch_bounds__(1024) void k_scan_blocks(uint32_t* block_sum, uint3
 __device__ __forceinline__ uint32_t prefix_at(const uint32_t* pre, const uint32_t* block_sum, uint32_t p) {
   return pre[p] + block_sum[p >> 8];
 }
-__global__ void k_children(WNode* wn, uint32_t m, WNode* next, const uint32_t* pre, const uint8_t* flag, const uint32_t* block_sum,
-                           Glob* g) {
+__global__ void k_children(WNode* wn, uint32_t m, WNode* next, uint32_t next_cap, const uint32_t* pre, const uint8_t* flag,
+                           const uint32_t* block_sum, Glob* g) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= m) return;
   WNode& w = wn[i];
@@ -613,6 +613,10 @@ __global__ void k_children(WNode* wn, uint32_t m, WNode* next, const uint32_t* p
   const uint32_t n_left = prefix_at(pre, block_sum, w.e - 1u) + flag[w.e - 1u] - prefix_at(pre, block_sum, w.b);
   const uint32_t mid = w.b + n_left;
   const uint32_t s = atomicAdd(&g->n_next, 2u);
+  if (s + 2u > next_cap) {  // (build_tree sizes `next` for every level there can be: never seen, never trusted)
+    atomicOr(&g->bad, 2u);
+    return;
+  }
   atomicMax(&g->max_next, max(n_left, (w.e - w.b) - n_left));
   w.child0 = s;
   wnode_init(next[s], w.b, mid, w.me, 0);
@@ -660,6 +664,11 @@ struct DevBuf {
 // HIP error, a non-finite triangle): the caller uses TreeBuilder itself.
 inline bool build_tree(int device, const RtScene* s, uint32_t R, rtaccel::TreeBuilder& tb) {
   std::vector<uint32_t> tri, shape, owner;
+  {
+    size_t total = 0;
+    for (uint32_t i = R; i < s->nodes[R].skip; i++) total += s->nodes[i].n_shapes;
+    tri.reserve(total), shape.reserve(total), owner.reserve(total);
+  }
   for (uint32_t i = R; i < s->nodes[R].skip; i++) {
     const RtNode& nd = s->nodes[i];
     for (uint32_t k = 0; k < nd.n_shapes; k++) tri.push_back(nd.first_tri + k), shape.push_back(nd.first_shape + k), owner.push_back(i);
@@ -720,8 +729,11 @@ inline bool build_tree(int device, const RtScene* s, uint32_t R, rtaccel::TreeBu
   RT_DEV_TRY(hipMemcpyAsync(d_geom.p, s->tri_geom + t_lo, span * sizeof(RtTriGeom), hipMemcpyHostToDevice, st));
   RT_DEV_TRY(hipMemcpyAsync(d_tri.p, tri.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
   RT_DEV_TRY(hipMemcpyAsync(d_shape.p, shape.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
-  size_t w_cap = 1024;
-  if (!d_w.ensure(w_cap) || !d_w2.ensure(2 * w_cap) || !d_bins.ensure(w_cap * 3 * kBins) || !d_mlist.ensure(w_cap)) return false;
+  // A node that is split holds more than kLeafTris triangles, so no level has more than 2 n / (kLeafTris + 1) nodes: the
+  // per-level buffers are made for that once (growing them level by level was a hipFree -- a device-wide wait -- and a
+  // hipMalloc three times a level).
+  const size_t w_cap = std::max<size_t>(1024, 2 * ((size_t)n / (rtaccel::kLeafTris + 1)) + 16);
+  if (!d_w.ensure(w_cap) || !d_w2.ensure(w_cap) || !d_bins.ensure(w_cap * 3 * kBins) || !d_mlist.ensure(w_cap)) return false;
   hipLaunchKernelGGL(k_init, dim3(nb), dim3(256), 0, st, n, d_perm.p, d_node.p, d_w.p, d_g.p);
   hipLaunchKernelGGL(k_items, dim3(nb), dim3(256), 0, st, d_geom.p, d_tri.p, n, d_f.p, d_g.p);
   Glob& g = *pinned.p;
@@ -752,14 +764,14 @@ inline bool build_tree(int device, const RtScene* s, uint32_t R, rtaccel::TreeBu
     hipLaunchKernelGGL(k_flags, dim3(nb), dim3(256), 0, st, d_perm.p, d_node.p, d_f.p, d_shape.p, n, d_w.p, d_mflag.p, d_pre.p,
                        d_flag.p, d_bsum.p);
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, d_bsum.p, nb);
-    hipLaunchKernelGGL(k_children, dim3(mb), dim3(64), 0, st, d_w.p, m, d_w2.p, d_pre.p, d_flag.p, d_bsum.p, d_g.p);
+    hipLaunchKernelGGL(k_children, dim3(mb), dim3(64), 0, st, d_w.p, m, d_w2.p, (uint32_t)w_cap, d_pre.p, d_flag.p, d_bsum.p, d_g.p);
     hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(256), 0, st, d_perm.p, d_node.p, n, d_w.p, d_pre.p, d_flag.p, d_bsum.p, d_perm2.p,
                        d_node2.p);
     RT_DEV_TRY(hipGetLastError());
     RT_DEV_TRY(hipMemcpyAsync(&g, d_g.p, sizeof(g), hipMemcpyDeviceToHost, st));
     RT_DEV_TRY(hipStreamSynchronize(st));
     if (g.bad) {
-      if (timing) std::fprintf(stderr, "device tree: declined at depth %d (non-finite triangle)\n", depth);
+      if (timing) std::fprintf(stderr, "device tree: declined at depth %d (%s)\n", depth, (g.bad & 2u) ? "more nodes in a level than there can be" : "non-finite triangle");
       return false;
     }
     level_max = g.max_next;
@@ -769,16 +781,9 @@ inline bool build_tree(int device, const RtScene* s, uint32_t R, rtaccel::TreeBu
     if (m == 0) break;
     if (depth >= rtaccel::kMaxDepth) return false;  // cannot happen under k_split's rule
     depth++;
-    // the level after this one has at most 2 m nodes
     std::swap(d_w.p, d_w2.p);
     std::swap(d_w.cap, d_w2.cap);
-    if (d_w2.cap < 2 * (size_t)m) {
-      if (!d_w2.ensure(4 * (size_t)m)) return false;
-    }
-    if (d_bins.cap < (size_t)m * 3 * kBins) {
-      if (!d_bins.ensure((size_t)2 * m * 3 * kBins)) return false;
-    }
-    if (d_mlist.cap < (size_t)m && !d_mlist.ensure(2 * (size_t)m)) return false;
+    if ((size_t)m > w_cap) return false;  // (cannot happen: see w_cap)
   }
   stage("levels");
   const uint32_t n_nodes = g.n_nodes;
