@@ -525,14 +525,33 @@ int validate_scene(RtContext* ctx, const RtScene* s, bool* needs_big) {
   if (s->recursion_limit + 1 > RT_MAX_RAY_STACK) *needs_big = true;
   if (s->n_xforms < 1) return bad("xforms[0] (identity) missing");
   if (s->n_loose_shapes > s->n_shapes) return bad("n_loose_shapes > n_shapes");
-  for (uint32_t i = 0; i < s->n_shapes; i++) {
-    const RtShape& sh = s->shapes[i];
-    uint32_t kind = sh.kind_flags & RT_SHAPE_KIND_MASK;
-    if (kind > RT_SMOOTH_TRIANGLE) return bad("shape kind");
-    if (sh.xform >= s->n_xforms) return bad("shape xform index");
-    if (sh.material >= s->n_materials) return bad("shape material index");
-    if (sh.parent >= (int32_t)s->n_nodes || sh.parent < -1) return bad("shape parent index");
-    if (kind >= RT_TRIANGLE && sh.prim >= s->n_tris) return bad("shape prim index");
+  {
+    // (5.2 M records for dragons.yaml: in pieces on threads; the complaint is the one about the first bad shape)
+    const uint32_t n_pieces = s->n_shapes >= (1u << 18) ? std::max(1u, std::min(8u, std::thread::hardware_concurrency())) : 1u;
+    std::vector<std::pair<uint32_t, const char*>> first_bad(n_pieces, {0xFFFFFFFFu, nullptr});
+    auto piece = [&](uint32_t k) {
+      const uint32_t b = (uint32_t)((uint64_t)s->n_shapes * k / n_pieces), e = (uint32_t)((uint64_t)s->n_shapes * (k + 1) / n_pieces);
+      for (uint32_t i = b; i < e; i++) {
+        const RtShape& sh = s->shapes[i];
+        const uint32_t kind = sh.kind_flags & RT_SHAPE_KIND_MASK;
+        const char* what = kind > RT_SMOOTH_TRIANGLE                                 ? "shape kind"
+                           : sh.xform >= s->n_xforms                                 ? "shape xform index"
+                           : sh.material >= s->n_materials                           ? "shape material index"
+                           : (sh.parent >= (int32_t)s->n_nodes || sh.parent < -1)    ? "shape parent index"
+                           : (kind >= RT_TRIANGLE && sh.prim >= s->n_tris)           ? "shape prim index"
+                                                                                     : nullptr;
+        if (what) {
+          first_bad[k] = {i, what};
+          return;
+        }
+      }
+    };
+    std::vector<std::thread> pool;
+    for (uint32_t k = 1; k < n_pieces; k++) pool.emplace_back(piece, k);
+    piece(0);
+    for (auto& t : pool) t.join();
+    for (const auto& fb : first_bad)
+      if (fb.second) return bad(fb.second);
   }
   std::vector<uint32_t> depth(s->n_nodes, 0);
   for (uint32_t i = 0; i < s->n_nodes; i++) {
@@ -946,6 +965,7 @@ int rt_scene_create(RtContext* ctx, const RtScene* s, RtDeviceScene** out) {
     });
   });
   std::future<rtaccel::NodeCull> cull_job = std::async(std::launch::async, [s] { return rtaccel::build_node_cull(s); });
+  std::vector<std::vector<uint32_t>> piece_noshadow;  // shapes with shadow() == false, per piece of the pass below
   {
     // device copy of the shapes: bounded analytic shapes get a cull record (rt_accel.h), its index in `prim`.
     // 5.2 M records for dragons.yaml: the passes over all of them run in pieces on threads; whatever decides an index
@@ -966,6 +986,7 @@ int rt_scene_create(RtContext* ctx, const RtScene* s, RtDeviceScene** out) {
     {
       std::vector<std::vector<uint32_t>> candidates(n_pieces);  // cubes and spheres with enough siblings
       std::vector<uint32_t> piece_max(n_pieces, 0);
+      piece_noshadow.resize(n_pieces);
       in_pieces([&](uint32_t piece, uint32_t b, uint32_t e) {
         for (uint32_t i = b; i < e; i++) {
           shapes[i] = s->shapes[i];
@@ -978,6 +999,7 @@ int rt_scene_create(RtContext* ctx, const RtScene* s, RtDeviceScene** out) {
             if (siblings >= RT_CULL_MIN_SHAPES) candidates[piece].push_back(i);
           }
           if (shapes[i].vclass != RT_VCLASS_NEVER) piece_max[piece] = std::max(piece_max[piece], shapes[i].vclass);
+          if (!(shapes[i].kind_flags & RT_SHAPE_SHADOW)) piece_noshadow[piece].push_back(i);
         }
       });
       for (const std::vector<uint32_t>& list : candidates)
@@ -1001,17 +1023,20 @@ int rt_scene_create(RtContext* ctx, const RtScene* s, RtDeviceScene** out) {
       // only classes that occur more than once can have duplicates: count first (one pass), sort the few that remain
       uint32_t max_class = 0;
       for (uint32_t m : piece_max) max_class = std::max(max_class, m);
-      std::vector<uint8_t> seen((size_t)max_class + 1, 0);  // per class: 1 = seen once, 2 = more than once
-      for (uint32_t i = 0; i < s->n_shapes; i++)
-        // a triangle that holds a NaN equals no shape, itself included: it is nobody's duplicate
-        if ((shapes[i].kind_flags & RT_SHAPE_KIND_MASK) >= RT_TRIANGLE && shapes[i].vclass != RT_VCLASS_NEVER &&
-            seen[shapes[i].vclass] < 2)
-          seen[shapes[i].vclass]++;
+      std::vector<uint8_t> seen((size_t)max_class + 1, 0);  // per class: 1 = seen once, 2 and more = more than once
+      in_pieces([&](uint32_t, uint32_t b, uint32_t e) {
+        for (uint32_t i = b; i < e; i++)
+          // a triangle that holds a NaN equals no shape, itself included: it is nobody's duplicate
+          // (a count stops being raised once somebody sees 2: with one thread per piece it stays below 2 + their number)
+          if ((shapes[i].kind_flags & RT_SHAPE_KIND_MASK) >= RT_TRIANGLE && shapes[i].vclass != RT_VCLASS_NEVER &&
+              __atomic_load_n(&seen[shapes[i].vclass], __ATOMIC_RELAXED) < 2)
+            __atomic_fetch_add(&seen[shapes[i].vclass], (uint8_t)1, __ATOMIC_RELAXED);
+      });
       std::vector<std::vector<std::pair<uint64_t, uint32_t>>> piece_keyed(n_pieces);
       in_pieces([&](uint32_t piece, uint32_t b, uint32_t e) {
         for (uint32_t i = b; i < e; i++)
           if ((shapes[i].kind_flags & RT_SHAPE_KIND_MASK) >= RT_TRIANGLE && shapes[i].vclass != RT_VCLASS_NEVER &&
-              seen[shapes[i].vclass] == 2) {
+              seen[shapes[i].vclass] >= 2) {
             const int32_t par = shapes[i].parent;
             const int64_t anchor = par >= 0 ? (int64_t)s->nodes[par].next_xf + 1 : 0;
             piece_keyed[piece].emplace_back(((uint64_t)shapes[i].vclass << 32) | (uint64_t)anchor, i);
@@ -1050,8 +1075,8 @@ int rt_scene_create(RtContext* ctx, const RtScene* s, RtDeviceScene** out) {
     stage("auxiliary trees (wait)");
     std::vector<RtNode> nodes(s->nodes, s->nodes + s->n_nodes);
     // groups that hold a shape with shadow() == false somewhere below them (any-shadow search, rt_device.h)
-    for (uint32_t i = 0; i < s->n_shapes; i++)
-      if (!(s->shapes[i].kind_flags & RT_SHAPE_SHADOW)) {
+    for (const std::vector<uint32_t>& list : piece_noshadow)  // (noted by the pass over the shapes above)
+      for (uint32_t i : list) {
         d.props |= RT_SCENE_HAS_NOSHADOW;
         for (int32_t g = s->shapes[i].parent; g >= 0 && !(nodes[g].flags & RT_NODE_HAS_NOSHADOW); g = nodes[g].parent)
           nodes[g].flags |= RT_NODE_HAS_NOSHADOW;
