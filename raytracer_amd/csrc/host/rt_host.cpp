@@ -21,6 +21,7 @@
 #include <cstring>
 #include <deque>
 #include <functional>
+#include <future>
 #include <limits>
 #include <map>
 #include <memory>
@@ -677,8 +678,32 @@ struct RtbWorld {
   };
   std::vector<MoreGpu> more;
 
+  // The device context of a world that gets a big mesh is made on a thread of its own while the caller goes on building
+  // the world: the first context of a process loads the library's code object and takes 0.15 s, as long as building and
+  // flattening dragons.yaml.  (No GPU: the attempt fails as it would have later, and rth_device_scene reports it.)
+  std::future<std::pair<int, RtContext*>> ctx_job;
+  void ctx_early() {
+    if (ctx || ctx_job.valid()) return;
+    const int dev = device;
+    ctx_job = std::async(std::launch::async, [dev] {
+      RtContext* c = nullptr;
+      const int rc = rt_context_create(dev, &c);
+      return std::make_pair(rc, rc == RT_OK ? c : (RtContext*)nullptr);
+    });
+  }
+  void ctx_collect() {  // what ctx_early started, if anything, is ours now
+    if (!ctx_job.valid()) return;
+    const std::pair<int, RtContext*> r = ctx_job.get();
+    if (r.second) {
+      if (ctx)
+        rt_context_destroy(r.second);
+      else
+        ctx = r.second;
+    }
+  }
   ~RtbWorld() { drop_device(); }
   void drop_device() {
+    ctx_collect();
     if (dscene) rt_scene_destroy(ctx, dscene);
     dscene = nullptr;
     if (ctx) rt_context_destroy(ctx);
@@ -1952,6 +1977,7 @@ int rth_group_add_mesh(RtbWorld* w, int g, const RtbMaterial* material, const fl
                        const float* normals, int nnormals, const int32_t* vidx, const int32_t* nidx, int ntriangles) {
   if (g < 0 || g >= (int)w->groups.size()) return fail(w, "bad group handle");
   if (npositions < 0 || nnormals < 0 || ntriangles < 0) return fail(w, "negative mesh size");
+  if (ntriangles >= 65536) w->ctx_early();
   const bool has_n = normals && nidx;
   // the same arrays handed in again (scene.rs:593-599 re-parses the file for every `obj:` use): one HMesh
   // (hashed and compared in 1 MB pieces on threads: dragons.yaml hands the same 31 MB in six times)
@@ -2250,8 +2276,11 @@ int rth_make_camera(RtbWorld* w, const RtbCamera* cam, RtCamera* out) {
 // Ensures the world is flattened and resident on its device; returns the C-ABI handles.
 int rth_device_scene(RtbWorld* w, RtContext** ctx, RtDeviceScene** scene) {
   if (!w->flatten()) return fail(w, "flatten failed");
+  w->ctx_collect();
   if (!w->ctx) {
+    const auto t0 = std::chrono::steady_clock::now();
     int rc = rt_context_create(w->device, &w->ctx);
+    if (std::getenv("RT_TIMING")) std::fprintf(stderr, "rt_context_create: %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     if (rc != RT_OK) return fail(w, "rt_context_create failed (is a GPU visible?)", rc);
   }
   if (!w->dscene) {
