@@ -587,6 +587,13 @@ __device__ __forceinline__ int reported_shape(const Scene& sc, int s) {
   return (w0.x & RT_SHAPE_KIND_MASK) >= RT_TRIANGLE ? (int)w1.z : s;
 }
 
+// Fused forms for the library's OWN tests (cull records): these are not the reference's arithmetic, nothing has to
+// round as rustc's code does, and a fused multiply-add only rounds less.  (The kernels are compiled with
+// -ffp-contract=off: nothing else in them is ever fused.)
+__device__ __forceinline__ float dot_fused(V3 a, V3 b) { return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x)); }
+__device__ __forceinline__ V3 cross_fused(V3 a, V3 b) {
+  return v3(__builtin_fmaf(a.y, b.z, -(a.z * b.y)), __builtin_fmaf(a.z, b.x, -(a.x * b.z)), __builtin_fmaf(a.x, b.y, -(a.y * b.x)));
+}
 // The local_intersect of a shape's kind (shapes.rs:208-245) on a ray in the shape's space.
 template <class Sink>
 __device__ __forceinline__ void shape_test_local(const Scene& sc, uint32_t si, uint32_t kf, uint32_t prim, float mn, float mx,
@@ -624,11 +631,11 @@ __device__ __forceinline__ void shape_intersect(const Scene& sc, uint32_t si, co
     const f4n RT_CONST_AS* q = cst(reinterpret_cast<const f4n*>(sc.shape_cull)) + 3u * (size_t)prim;
     const f4n c0 = q[0], c1 = q[1], c2 = q[2];
     const V3 oc = v3(c0.x, c0.y, c0.z) - ray.o;
-    const V3 cr = cross(oc, ray.d);
-    const float ol2 = dot(oc, oc);
-    const float dl = __builtin_amdgcn_sqrtf(dot(ray.d, ray.d)), ol = __builtin_amdgcn_sqrtf(ol2);
-    const float thr = (dl * (((c0.w + c1.x * ol) + c1.y) + c1.z * ol2) + (c1.w * ol + c2.x)) * 1.0001f;
-    if (dot(cr, cr) > thr * thr) return;
+    const V3 cr = cross_fused(oc, ray.d);
+    const float ol2 = dot_fused(oc, oc);
+    const float dl = __builtin_amdgcn_sqrtf(dot_fused(ray.d, ray.d)), ol = __builtin_amdgcn_sqrtf(ol2);
+    const float thr = __builtin_fmaf(dl, __builtin_fmaf(c1.z, ol2, __builtin_fmaf(c1.x, ol, c0.w) + c1.y), __builtin_fmaf(c1.w, ol, c2.x)) * 1.0001f;
+    if (dot_fused(cr, cr) > thr * thr) return;
   }
   float mn = __uint_as_float(w1.z), mx = __uint_as_float(w1.w);
   Ray local = xform ? xf_ray(sc, xform, ray) : ray;
@@ -1279,11 +1286,12 @@ __device__ RT_WI_INLINE void world_intersect(const Scene& sc, const Ray& ray, Si
           const f4n RT_CONST_AS* q = cst(reinterpret_cast<const f4n*>(sc.node_cull)) + 3u * (size_t)w3.z;
           const f4n c0 = q[0], c1 = q[1], c2 = q[2];
           const V3 oc = v3(c0.x, c0.y, c0.z) - cur.o;
-          const V3 cr = cross(oc, cur.d);
-          const float ol2 = dot(oc, oc);
-          const float dl = __builtin_amdgcn_sqrtf(dot(cur.d, cur.d)), ol = __builtin_amdgcn_sqrtf(ol2);
-          const float thr = (dl * (((c0.w + c1.x * ol) + c1.z * ol2) + dl * (c2.y * ol + c2.z)) + (c1.w * ol + c2.x)) * 1.0001f;
-          culled = dot(cr, cr) > thr * thr;
+          const V3 cr = cross_fused(oc, cur.d);
+          const float ol2 = dot_fused(oc, oc);
+          const float dl = __builtin_amdgcn_sqrtf(dot_fused(cur.d, cur.d)), ol = __builtin_amdgcn_sqrtf(ol2);
+          const float inner = __builtin_fmaf(dl, __builtin_fmaf(c2.y, ol, c2.z), __builtin_fmaf(c1.z, ol2, __builtin_fmaf(c1.x, ol, c0.w)));
+          const float thr = __builtin_fmaf(dl, inner, __builtin_fmaf(c1.w, ol, c2.x)) * 1.0001f;
+          culled = dot_fused(cr, cr) > thr * thr;
         }
         if (!culled) {
           if (COUNT) cn.node_visits++;
