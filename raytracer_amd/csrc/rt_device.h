@@ -55,6 +55,7 @@ struct Lim {
 #define RT_SCENE_AREA_LIGHT 0x8u   // Scene::props: some area light takes more than one sample
 #define RT_SCENE_HAS_PATTERN 0x80u  // Scene::props: some material has a pattern
 #define RT_SCENE_OTHER_LIGHT 0x100u // Scene::props: some light is not a point light
+#define RT_SCENE_HAS_COPIES 0x200u  // Scene::props: some triangle is listed more than once (end_of_copy_run)
 // What a job-loop kernel is compiled with (integrate<.., FEAT>, world_intersect<.., FEAT>): the launch picks the
 // instantiation with the fewest features that still covers the scene (rt_hip.hip jobs_kernel)
 #define RT_F_CSG 1u      // csg trees (world.rs:45-49)
@@ -578,14 +579,6 @@ struct SinkT {
   __device__ __forceinline__ bool done() const { return mode == SINK_ANY_SHADOW && found(); }
 };
 typedef SinkT<XsList> Sink;
-
-// The shape reported for a hit on `s`: the last of its value-identical duplicates (rt_scene_create; triangles only,
-// the index sits in the record's unused min slot).  Shading does not care which of them it is.
-__device__ __forceinline__ int reported_shape(const Scene& sc, int s) {
-  if (s < 0) return s;
-  const u4n w0 = cst(reinterpret_cast<const u4n*>(sc.shapes + s))[0], w1 = cst(reinterpret_cast<const u4n*>(sc.shapes + s))[1];
-  return (w0.x & RT_SHAPE_KIND_MASK) >= RT_TRIANGLE ? (int)w1.z : s;
-}
 
 // Fused forms for the library's OWN tests (cull records): these are not the reference's arithmetic, nothing has to
 // round as rustc's code does, and a fused multiply-add only rounds less.  (The kernels are compiled with
@@ -1222,6 +1215,63 @@ __device__ inline Ray ray_in_space_of(const Scene& sc, int xf_node, const Ray& w
   for (int k = n - 1; k >= 0; k--) r = xf_ray(sc, cst(sc.nodes)[chain[k]].xform, r);
   return r;
 }
+// Which of several value-identical triangles a hit is booked on.  A mesh that lists a triangle twice gives two entries
+// equal in (t, Shape, u, v); the reference's Intersections is a BTreeMap built in bulk from the list sorted by t
+// (stable: insertion order within one t), and that build drops an entry that is == its SUCCESSOR.  So of
+// the entries at the hit's t, in insertion order, the hit is the last of the first run of equal neighbours: the sink's
+// winner `w` (lowest rank at that t) gives way to its next copy -- the next triangle of the same value class under the
+// same transformed ancestor, linked through the record's unused min slot by rt_scene_create -- unless some entry in
+// between has the very same t (one made of the same vertices in another order, say).  The entries in between are the
+// other shapes of w's group (shapes before children, groups.rs:118-123) or, for a loose shape, loose shapes: each is
+// intersected with the ray the walk gave that group.  Exact for copies within one group and for loose copies; a copy in
+// ANOTHER group under the same ancestor is taken over without looking at what lies between (their boxes may differ),
+// and so is one more than RT_COPY_GAP_MAX places on.  Not part of the render kernels: a pass of its own over the ids
+// (rt_hip.hip k_copies_pixels / k_copies_rays), only for scenes with copies and callers that ask for ids.
+#ifndef RT_COPY_GAP_MAX
+#define RT_COPY_GAP_MAX 65536
+#endif
+struct SameT {
+  float t0;
+  bool found;
+  __device__ __forceinline__ bool takes(uint32_t) const { return true; }
+  __device__ __forceinline__ void add(float tt, uint32_t, float, float) { found = found || of_eq(tt, t0); }
+};
+__device__ inline int next_copy(const Scene& sc, int s) {
+  const u4n w0 = cst(reinterpret_cast<const u4n*>(sc.shapes + s))[0], w1 = cst(reinterpret_cast<const u4n*>(sc.shapes + s))[1];
+  return (w0.x & RT_SHAPE_KIND_MASK) >= RT_TRIANGLE ? (int)w1.z : s;
+}
+__device__ inline int end_of_copy_run(const Scene& sc, const Ray& world, int w) {
+  int next = next_copy(sc, w);
+  if (next == w) return w;
+  const u4n w0 = cst(reinterpret_cast<const u4n*>(sc.shapes + w))[0], w1 = cst(reinterpret_cast<const u4n*>(sc.shapes + w))[1];
+  int parent = (int)w0.w;
+  // the ray in the space of w's group, through the same chain of transforms as the walk (same bits), and the hit's t
+  const Ray local = parent >= 0 ? ray_in_space_of<true>(sc, cst(sc.nodes)[parent].next_xf, world) : world;
+  float t0, u, v;
+  {
+    V3 p1, e1, e2;
+    load_tri(sc, w1.y, p1, e1, e2);
+    if (!isect_triangle(w0.y ? xf_ray(sc, w0.y, local) : local, p1, e1, e2, t0, u, v)) return w;
+  }
+  const int first_loose = (int)(sc.n_shapes - sc.n_loose);
+  while (next != w) {
+    const int next_parent = cst(sc.shapes)[next].parent;
+    if (next_parent == parent && next - w - 1 <= RT_COPY_GAP_MAX) {
+      SameT between{t0, false};
+      for (int k = w + 1; k < next && !between.found; k++) {
+        // (a shape without a group that is not loose is the leaf of a csg: its entries are the csg's business)
+        if (cst(sc.shapes)[k].parent != parent || (parent < 0 && k < first_loose)) continue;
+        shape_intersect<false>(sc, (uint32_t)k, local, between);
+      }
+      if (between.found) break;
+    }
+    parent = next_parent;
+    w = next;
+    next = next_copy(sc, w);
+  }
+  return w;
+}
+
 // The walk is WAVE-SYNCHRONOUS: every lane walks the same DFS order and lanes differ only in the
 // subtrees they skip, so the node index is kept uniform across the wave (all node, transform, shape and
 // triangle records of the reference tree are then fetched with scalar loads, off the vector-memory
@@ -1946,7 +1996,7 @@ __device__ inline void integrate(const Scene& sc, const RenderParams& rp, const 
           // outputs of the primary hit go out now instead of riding along in registers; (u, v) exist for smooth
           // triangles only (intersections.rs:34-41)
           const bool smooth = (kf & RT_SHAPE_KIND_MASK) == RT_SMOOTH_TRIANGLE;
-          src.first_hit(item, Hit{hit.t, smooth ? hit.u : 0.f, smooth ? hit.v : 0.f, reported_shape(sc, hit.shape)});
+          src.first_hit(item, Hit{hit.t, smooth ? hit.u : 0.f, smooth ? hit.v : 0.f, hit.shape});  // (copies of a triangle: rt_hip.hip k_copies_*)
           first = false;
         }
         V3 point = sray.o + hit.t * sray.d;

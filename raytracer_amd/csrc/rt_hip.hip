@@ -271,7 +271,6 @@ void k_render_direct(Scene sc, RtCamera cam, RenderParams rp, PartInfo part, Pix
     if (COUNT) cn.ref_rays = 1;
     Hit ph;
     V3 col = color_at_direct<COUNT, HOIST>(sc, rp, ray_for_pixel(cam, px, py), sc.recursion_limit, py * cam.hsize + px, cn, &ph);
-    ph.shape = reported_shape(sc, ph.shape);
     write_hit(o, (size_t)ly * cam.hsize + px, ph);
     write_colour<COUNT>(sc, o, (size_t)ly * cam.hsize + px, col,
                         (float)(cn.node_visits + cn.aux_tests + cn.tri_tests + cn.shape_tests), (float)cn.work_shadow,
@@ -339,10 +338,31 @@ __global__ __launch_bounds__(RT_BLOCK) void k_color_at_direct(Scene sc, RenderPa
     Hit ph;
     V3 col = color_at_direct<false>(sc, rp, r, remaining, i, cn, &ph);
     write_ray_colour(o, i, col);
-    ph.shape = reported_shape(sc, ph.shape);
     write_ray_hit(o, i, ph);
   }
   flush_counters(cn, counters, sc.sticky);
+}
+
+// The ids of primary hits on a triangle that is listed more than once (rt_device.h end_of_copy_run): a pass over the
+// ids the render kernels wrote, launched only for scenes with such triangles and callers that ask for ids.  Nearly
+// every thread is done after one look at its shape's record.
+__global__ __launch_bounds__(256) void k_copies_pixels(Scene sc, RtCamera cam, PartInfo part, int32_t* __restrict__ oid) {
+  const size_t idx = (size_t)blockIdx.x * 256u + threadIdx.x;
+  if (idx >= (size_t)part.rows * cam.hsize) return;
+  const int w = oid[idx];
+  if (w < 0 || next_copy(sc, w) == w) return;
+  const uint32_t ly = (uint32_t)(idx / cam.hsize), px = (uint32_t)(idx % cam.hsize);
+  const uint32_t py = (ly / part.tile_h) * (part.n_parts * part.tile_h) + part.part * part.tile_h + (ly % part.tile_h);
+  oid[idx] = end_of_copy_run(sc, ray_for_pixel(cam, px, py), w);
+}
+__global__ __launch_bounds__(256) void k_copies_rays(Scene sc, RayOut o) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= o.n) return;
+  const int w = o.hit_id[i];
+  if (w < 0 || next_copy(sc, w) == w) return;
+  const Ray r{v3(o.origins[3 * i], o.origins[3 * i + 1], o.origins[3 * i + 2]),
+              v3(o.directions[3 * i], o.directions[3 * i + 1], o.directions[3 * i + 2])};
+  o.hit_id[i] = end_of_copy_run(sc, r, w);
 }
 
 // What the reference does with the canvas after Camera::render (scene.rs:215-224), on the device: ordered dithering
@@ -992,7 +1012,7 @@ int rt_scene_create(RtContext* ctx, const RtScene* s, RtDeviceScene** out) {
           shapes[i] = s->shapes[i];
           const uint32_t kind = shapes[i].kind_flags & RT_SHAPE_KIND_MASK;
           if (kind >= RT_TRIANGLE) {
-            memcpy(&shapes[i].mn, &i, sizeof(uint32_t));  // reported_shape: itself, until a later duplicate is found
+            memcpy(&shapes[i].mn, &i, sizeof(uint32_t));  // next_copy: itself, until a later duplicate is found
           } else if (kind == RT_CUBE || kind == RT_SPHERE) {
             const int32_t par = shapes[i].parent;
             const uint32_t siblings = par >= 0 ? s->nodes[par].n_shapes : s->n_loose_shapes;
@@ -1011,12 +1031,12 @@ int rt_scene_create(RtContext* ctx, const RtScene* s, RtDeviceScene** out) {
             cull.insert(cull.end(), rec, rec + 12);
           }
         }
-      // Which of several value-identical triangles is reported as hit (rt_device.h reported_shape). A mesh that lists
+      // Which of several value-identical triangles is reported as hit (rt_device.h end_of_copy_run). A mesh that lists
       // a triangle twice gives two entries equal in (t, Shape, u, v), and of such neighbours the reference's
       // Intersections keeps the LATER one (BTreeMap bulk build), whereas ties between different shapes
       // go to the earlier. Duplicates are the same class under the same transformed ancestor; the device copy of a
-      // triangle holds the last of them in the unused `mn` slot.  Duplicates that sit in DIFFERENT groups are merged
-      // too: exact whenever the ray that hits both also passes both groups' box tests, which holds for every mesh
+      // triangle holds the NEXT of them in the unused `mn` slot (itself: none).  Duplicates that sit in DIFFERENT groups
+      // are linked too: exact whenever the ray that hits both also passes both groups' box tests, which holds for every mesh
       // `divide` builds (equal triangles have equal boxes and take the same side at every split); for hand-placed
       // duplicates in groups with different boxes a ray within rounding of one box's face may report the other id
       // (the id only: the shapes are equal, so is the colour).
@@ -1048,7 +1068,8 @@ int rt_scene_create(RtContext* ctx, const RtScene* s, RtDeviceScene** out) {
       for (size_t a = 0; a < keyed.size();) {
         size_t b = a + 1;
         while (b < keyed.size() && keyed[b].first == keyed[a].first) b++;
-        for (size_t k = a; k + 1 < b; k++) memcpy(&shapes[keyed[k].second].mn, &keyed[b - 1].second, sizeof(uint32_t));
+        for (size_t k = a; k + 1 < b; k++) memcpy(&shapes[keyed[k].second].mn, &keyed[k + 1].second, sizeof(uint32_t));
+        if (b - a > 1) d.props |= RT_SCENE_HAS_COPIES;
         a = b;
       }
     }
@@ -1255,6 +1276,10 @@ static int launch_part(RtContext* ctx, const Scene& sc, const RtCamera* cam, con
     if (sc.n_nodes == 0 && sc.n_shapes <= RT_LIGHT_SCENE_SHAPES)
       rq.queue_chunk = (uint32_t)std::clamp<uint64_t>(items / 64u / (waves * RT_LIGHT_SCENE_DRAWS), 1u, RT_LIGHT_SCENE_CHUNK);
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(RT_BLOCK), 0, stream, sc, *cam, rq, part, po, d_counters);
+  }
+  if ((sc.props & RT_SCENE_HAS_COPIES) && po.oid) {
+    const size_t n = (size_t)part.rows * cam->hsize;
+    hipLaunchKernelGGL(k_copies_pixels, dim3((uint32_t)((n + 255u) / 256u)), dim3(256), 0, stream, sc, *cam, part, po.oid);
   }
   HIP_TRY(ctx, hipGetLastError());
   return side_leave(ctx, stream);
@@ -1892,6 +1917,8 @@ trace_again:
     if (sc.side_cap) kern = k_color_at_jobs<true, true, true>;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(RT_BLOCK), 0, ctx->stream, sc, rp, ro, remaining, block);
   }
+  if ((sc.props & RT_SCENE_HAS_COPIES) && hit_id && n)
+    hipLaunchKernelGGL(k_copies_rays, dim3((n + 255u) / 256u), dim3(256), 0, ctx->stream, sc, ro);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   {
