@@ -987,3 +987,32 @@ def test_a_coincident_triangle_between_two_copies_of_a_triangle(order, expected,
     r = build(_oracle().new_world()).render(cam, aux=True)
     check(g, r, f"copies {order} {where}")
     assert len(np.unique(r.object_id)) >= 2
+
+
+def test_copies_of_a_triangle_in_parts():
+    """The pass over the ids (k_copies_pixels) finds a pixel's ray from its row in the PART: interleaved parts of a
+    frame whose every pixel needs the pass give the ids of the whole frame, which are the oracle's."""
+    from raytracer_amd import tiles
+
+    class Copies:
+        def build(self, w):
+            g = w.group([("rotate-z", 0.3)])
+            for c in "aaxaxa":
+                w.group_add_shape(g, w.shape("triangle", (), None, params=_COPY_A if c == "a" else _COPY_X))
+            w.add_group(g)
+            w.add_point_light((0, 5, 10), (1, 1, 1))
+            return w
+
+        def camera(self, hsize, vsize):
+            return B.Camera(hsize, vsize, 0.9, (1.2, 1.1, 6.0), (1.2, 1.1, 0.0), (0, 1, 0))
+
+    raw = Raw(Copies(), (70, 45))
+    _, ids, _ = raw.render()
+    r = Copies().build(_oracle().new_world()).render(Copies().camera(70, 45), aux=True)
+    assert np.array_equal(ids, r.object_id) and (ids >= 0).mean() > 0.2
+    for n, tile_h in ((3, 2), (4, 1), (2, 8)):
+        idc = np.empty_like(ids)
+        for p in range(n):
+            _, oid, _ = raw.render(tile_h=tile_h, n_parts=n, part=p)
+            idc[tiles.part_rows(45, tile_h, n, p)] = oid
+        assert np.array_equal(idc, ids), (n, tile_h)
