@@ -1,6 +1,6 @@
 """Exactness fuzz on the GPU: random worlds of cubes and spheres (tests/test_gpu_parity.py _random_solids) and
 small-dragon scenes with random cameras, random rays through rt_color_at, hit ids and t against the oracle.
-usage: gpu_fuzz.py [first_seed] [n_seeds]"""
+usage: gpu_fuzz.py [frames | parts | few | copies] [first_seed] [n_seeds]"""
 import os
 import sys
 
@@ -274,6 +274,78 @@ def run_few(seed, log=print):
     return 0
 
 
+def copies_world(w, rng):
+    """Triangles listed more than once, next to triangles of the same corners in another order (another Shape, often
+    the very same t) and the odd sphere: one to three groups, each under a transform of its own, and loose shapes --
+    the arrangements whose ids rt_device.h end_of_copy_run gets exactly (copies within one group, loose copies)."""
+    import itertools
+    perms = list(itertools.permutations(range(3)))
+
+    def fill(add):
+        exact = rng.randint(2) == 0  # small integers: every corner order gives the same t far more often
+        pool = []
+        for _ in range(int(rng.randint(1, 4))):
+            c = rng.randint(-3, 4, size=(3, 3)).astype(float) if exact else rng.uniform(-3, 3, size=(3, 3))
+            c[:, 2] = c[:, 2] * 0.25
+            pool.append(c)
+        smooth = rng.randint(4) == 0
+        for _ in range(int(rng.randint(2, 12))):
+            if rng.randint(8) == 0:
+                add(w.shape("sphere", [("scale", *rng.uniform(0.3, 1.5, 3)), ("translate", *rng.uniform(-2, 2, 3))], None))
+                continue
+            c = pool[int(rng.randint(len(pool)))][list(perms[int(rng.randint(6)) if rng.randint(2) else 0])]
+            if smooth:
+                add(w.shape("smooth-triangle", (), None, params=list(c.ravel()) + [0, 0, -1, 0.1, 0, -1, 0, 0.1, -1]))
+            else:
+                add(w.shape("triangle", (), None, params=list(c.ravel())))
+
+    for _ in range(int(rng.randint(1, 4))):
+        ops = [("rotate-y", rng.uniform(-0.5, 0.5)), ("translate", *rng.uniform(-3, 3, 3))] if rng.randint(2) else \
+              [("translate", *(rng.randint(-6, 7, 3) * 0.5))]
+        g = w.group(ops)
+        fill(lambda sh: w.group_add_shape(g, sh))
+        w.add_group(g)
+    if rng.randint(2):
+        fill(w.add_shape)
+    w.add_point_light(tuple(rng.uniform(-10, 10, 3)), (1, 1, 1))
+
+
+def run_copies(seed, log=print):
+    """A copies_world frame and 4 000 random rays against the oracle."""
+    from raytracer_amd import builder as B
+    from test_gpu_parity import check
+    rng = np.random.RandomState(13000 + seed)
+    gw, ow = host.new_world(0), oracle.new_world()
+    copies_world(gw, np.random.RandomState(seed))
+    copies_world(ow, np.random.RandomState(seed))
+    eye = np.array([rng.uniform(-3, 3), rng.uniform(-3, 3), rng.choice([-9.0, 9.0])])
+    if rng.randint(2):
+        eye = np.round(eye)
+    cam = B.Camera(int(rng.randint(17, 200)), int(rng.randint(9, 120)), float(rng.uniform(0.5, 1.3)), tuple(eye),
+                   (0, 0, 0), (0, 1, 0))
+    g = gw.render(cam, aux=True)
+    r = ow.render(cam, aux=True)
+    o = np.tile(eye.astype(np.float32), (4000, 1))
+    target = rng.randint(-6, 7, size=(4000, 3)) * 0.5 if rng.randint(2) else rng.uniform(-3, 3, size=(4000, 3))
+    d = (target - eye).astype(np.float32)
+    if rng.randint(2):  # axis-parallel rays through half-integer points
+        o = np.column_stack([target[:, 0], target[:, 1], np.full(4000, eye[2])]).astype(np.float32)
+        d = np.tile(np.array([[0, 0, -np.sign(eye[2])]], dtype=np.float32), (4000, 1))
+    _, gt, gid, guv = gw.color_at(o, d, 1)
+    _, rt, rid, ruv = ow.color_at(o, d, 1)
+    try:
+        check(g, r, f"copies seed {seed}")
+        assert np.array_equal(gid, rid), f"ray ids differ at {np.nonzero(gid != rid)[0][:5]}"
+        hit = rid >= 0
+        assert np.array_equal(gt[hit].view(np.uint32), rt[hit].view(np.uint32)), "ray t differs"
+    except AssertionError as e:
+        log(f"copies seed {seed} {cam.hsize}x{cam.vsize}: FAIL {e}")
+        return 1
+    moved = int((r.object_id >= 0).sum())
+    log(f"copies seed {seed} {cam.hsize}x{cam.vsize}: ok, pixels hit {moved}, rays hit {int((rid >= 0).sum())}")
+    return 0
+
+
 class _FuzzScene:
     """What tests/test_gpu_parity.py Raw needs of a scene: build(world) and camera(w, h)."""
 
@@ -318,6 +390,11 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "parts":
         first, count = int(sys.argv[2]), int(sys.argv[3])
         bad = sum(run_parts(seed, log=lambda m: print(m, flush=True)) for seed in range(first, first + count))
+        print("failures:", bad)
+        sys.exit(1 if bad else 0)
+    if len(sys.argv) > 1 and sys.argv[1] == "copies":
+        first, count = int(sys.argv[2]), int(sys.argv[3])
+        bad = sum(run_copies(seed, log=lambda m: print(m, flush=True)) for seed in range(first, first + count))
         print("failures:", bad)
         sys.exit(1 if bad else 0)
     if len(sys.argv) > 1 and sys.argv[1] == "few":
