@@ -1221,11 +1221,13 @@ __device__ inline Ray ray_in_space_of(const Scene& sc, int xf_node, const Ray& w
 // the entries at the hit's t, in insertion order, the hit is the last of the first run of equal neighbours: the sink's
 // winner `w` (lowest rank at that t) gives way to its next copy -- the next triangle of the same value class under the
 // same transformed ancestor, linked through the record's unused min slot by rt_scene_create -- unless some entry in
-// between has the very same t (one made of the same vertices in another order, say).  The entries in between are the
-// other shapes of w's group (shapes before children, groups.rs:118-123) or, for a loose shape, loose shapes: each is
-// intersected with the ray the walk gave that group.  Exact for copies within one group and for loose copies; a copy in
-// ANOTHER group under the same ancestor is taken over without looking at what lies between (their boxes may differ),
-// and so is one more than RT_COPY_GAP_MAX places on.  Not part of the render kernels: a pass of its own over the ids
+// between has the very same t (one made of the same vertices in another order, say), or the copy is not an entry at
+// all (its group's box, or one above it, is missed by the ray).  So this walks on from w in insertion order exactly as
+// the reference gathers entries (groups depth-first, shapes before children, groups.rs:111-123, with the reference's
+// own box tests and rays; then the loose shapes, world.rs:56-59), intersects every shape it passes and stops at the
+// first with that t that is not the next copy.  What it does not look at: the leaves of a csg (a csg's entries are not
+// its leaves' -- a leaf that is a copy is taken over unseen), and anything after RT_COPY_GAP_MAX shapes (from there on
+// every further copy is taken over unseen).  Not part of the render kernels: a pass of its own over the ids
 // (rt_hip.hip k_copies_pixels / k_copies_rays), only for scenes with copies and callers that ask for ids.
 #ifndef RT_COPY_GAP_MAX
 #define RT_COPY_GAP_MAX 65536
@@ -1243,32 +1245,87 @@ __device__ inline int next_copy(const Scene& sc, int s) {
 __device__ inline int end_of_copy_run(const Scene& sc, const Ray& world, int w) {
   int next = next_copy(sc, w);
   if (next == w) return w;
+  const int first_loose = (int)(sc.n_shapes - sc.n_loose);
+  // leaves of a csg come first in the order: copies among them are taken over unseen
+  while (next != w && cst(sc.shapes)[w].parent < 0 && w < first_loose && cst(sc.shapes)[next].parent < 0 && next < first_loose) {
+    w = next;
+    next = next_copy(sc, w);
+  }
+  if (next == w) return w;
   const u4n w0 = cst(reinterpret_cast<const u4n*>(sc.shapes + w))[0], w1 = cst(reinterpret_cast<const u4n*>(sc.shapes + w))[1];
-  int parent = (int)w0.w;
+  const int parent = (int)w0.w;
   // the ray in the space of w's group, through the same chain of transforms as the walk (same bits), and the hit's t
-  const Ray local = parent >= 0 ? ray_in_space_of<true>(sc, cst(sc.nodes)[parent].next_xf, world) : world;
+  const int anchor = parent >= 0 ? cst(sc.nodes)[parent].next_xf : -1;
+  Ray cur = anchor >= 0 ? ray_in_space_of<true>(sc, anchor, world) : world;
   float t0, u, v;
   {
     V3 p1, e1, e2;
     load_tri(sc, w1.y, p1, e1, e2);
-    if (!isect_triangle(w0.y ? xf_ray(sc, w0.y, local) : local, p1, e1, e2, t0, u, v)) return w;
+    if (!isect_triangle(w0.y ? xf_ray(sc, w0.y, cur) : cur, p1, e1, e2, t0, u, v)) return w;
   }
-  const int first_loose = (int)(sc.n_shapes - sc.n_loose);
-  while (next != w) {
-    const int next_parent = cst(sc.shapes)[next].parent;
-    if (next_parent == parent && next - w - 1 <= RT_COPY_GAP_MAX) {
-      SameT between{t0, false};
-      for (int k = w + 1; k < next && !between.found; k++) {
-        // (a shape without a group that is not loose is the leaf of a csg: its entries are the csg's business)
-        if (cst(sc.shapes)[k].parent != parent || (parent < 0 && k < first_loose)) continue;
-        shape_intersect<false>(sc, (uint32_t)k, local, between);
-      }
-      if (between.found) break;
+  int budget = RT_COPY_GAP_MAX;
+  // one shape of the order: 0 = go on, 1 = the run ends at w
+  auto pass = [&](int k, const Ray& r) -> int {
+    if (k <= w) return 0;
+    if (k == next) {  // the next copy is an entry and nothing at t0 lies between: the run goes on
+      w = next;
+      next = next_copy(sc, w);
+      return next == w ? 1 : 0;
     }
-    parent = next_parent;
-    w = next;
-    next = next_copy(sc, w);
+    if (budget-- <= 0) return 0;
+    SameT between{t0, false};
+    shape_intersect<false>(sc, (uint32_t)k, r, between);
+    return between.found ? 1 : 0;
+  };
+  // a copy that the order has passed without meeting it is not an entry (its group was not reached): on to the one after
+  auto passed = [&](int upto) -> int {  // every shape below `upto` is behind us; 1 = no copy is left
+    while (next < upto) {
+      const int n2 = next_copy(sc, next);
+      if (n2 == next) return 1;
+      next = n2;
+    }
+    return 0;
+  };
+  if (parent >= 0 || w < first_loose) {
+    uint32_t leave_at = anchor >= 0 ? cst(sc.nodes)[anchor].skip : 0xFFFFFFFFu;
+    uint32_t i = parent >= 0 ? (uint32_t)parent : 0u;
+    bool reached = parent >= 0;  // w's own group: the ray got there, and `cur` is the ray it was given
+    const uint32_t end = anchor >= 0 ? cst(sc.nodes)[anchor].skip : sc.n_nodes;  // copies share the transformed ancestor
+    while (i < end) {
+      const u4n RT_CONST_AS* raw = cst(reinterpret_cast<const u4n*>(sc.nodes + i));
+      const u4n n0 = raw[0], n1 = raw[1], n2 = raw[2];
+      const uint32_t xform = n0.w, first_shape = n2.x, n_shapes = n2.y, skip = n2.z;
+      if (passed((int)first_shape)) return w;
+      bool descend = reached;
+      if (!reached) {
+        if (i >= leave_at) {
+          const int par = (int)n2.w;
+          const int q = par >= 0 ? cst(sc.nodes)[par].next_xf : -1;
+          cur = q >= 0 ? ray_in_space_of<true>(sc, q, world) : world;
+          leave_at = q >= 0 ? cst(sc.nodes)[q].skip : 0xFFFFFFFFu;
+        }
+        if (xform) {
+          cur = xf_ray(sc, xform, cur);
+          leave_at = skip;
+        }
+        float tmin, tmax;
+        descend = slab_decided(cur, v3(__uint_as_float(n0.x), __uint_as_float(n0.y), __uint_as_float(n0.z)),
+                               v3(__uint_as_float(n1.x), __uint_as_float(n1.y), __uint_as_float(n1.z)), tmin, tmax);  // groups.rs:111-113
+      }
+      reached = false;
+      if (descend) {
+        for (uint32_t k = 0; k < n_shapes; k++)
+          if (pass((int)(first_shape + k), cur)) return w;
+        i = i + 1u;
+      } else {
+        i = skip;
+      }
+    }
+    if (anchor >= 0) return w;  // (every copy is below the ancestor: whatever is left was not reached)
   }
+  if (passed(first_loose)) return w;
+  for (int k = first_loose > w ? first_loose : w + 1; k < (int)sc.n_shapes; k++)
+    if (pass(k, world)) return w;
   return w;
 }
 

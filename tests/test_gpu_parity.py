@@ -989,6 +989,43 @@ def test_a_coincident_triangle_between_two_copies_of_a_triangle(order, expected,
     assert len(np.unique(r.object_id)) >= 2
 
 
+@pytest.mark.parametrize("tree,expected", [
+    (("a", [("a",)]), 1),                     # a copy in a child group: neighbours all the same
+    (("a", [("x",), ("a",)]), 0),             # ... with another group's x at the same t between them
+    (("a", [("s",), ("a",)]), 2),             # ... with another group's sphere between them, met elsewhere
+    (("aa", [("xa",)]), 1),
+    (("", [("a", [("a",)]), ("a",), ("xa",)]), 2),
+])
+def test_copies_of_a_triangle_in_different_groups(tree, expected):
+    """Copies in different groups under one transformed ancestor are neighbours in the reference's list like any
+    others (groups depth-first, shapes before children): end_of_copy_run walks that order with the reference's own
+    box tests.  Ids are ranks: a group's shapes, then its children's."""
+    def make(w, spec):
+        g = w.group([("translate", 0, 0, 0)] if len(spec) < 3 else [("translate", 0.25, 0.5, 0)])
+        for c in spec[0]:
+            if c == "s":
+                w.group_add_shape(g, w.shape("sphere", [("translate", 1, 1, -3)], None))
+            else:
+                w.group_add_shape(g, w.shape("triangle", (), None, params=_COPY_A if c == "a" else _COPY_X))
+        for child in (spec[1] if len(spec) > 1 else []):
+            w.group_add_child(g, make(w, child))
+        return g
+
+    def build(w):
+        w.add_group(make(w, tree))
+        w.add_point_light((0, 5, 10), (1, 1, 1))
+        return w
+
+    o = np.array([[1.5, 1.5, 5.0]], dtype=np.float32)
+    d = np.array([[0.0, 0.0, -1.0]], dtype=np.float32)
+    _, gt, gid, _ = build(host.new_world(0)).color_at(o, d, 0)
+    _, rt_, rid, _ = build(_oracle().new_world()).color_at(o, d, 0)
+    assert gt[0] == rt_[0] == 5.0
+    assert rid[0] == expected and gid[0] == rid[0]
+    cam = B.Camera(48, 32, 0.9, (1.2, 1.1, 6.0), (1.2, 1.1, 0.0), (0, 1, 0))
+    check(build(host.new_world(0)).render(cam, aux=True), build(_oracle().new_world()).render(cam, aux=True), f"copies {tree}")
+
+
 def test_copies_of_a_triangle_in_parts():
     """The pass over the ids (k_copies_pixels) finds a pixel's ray from its row in the PART: interleaved parts of a
     frame whose every pixel needs the pass give the ids of the whole frame, which are the oracle's."""

@@ -274,22 +274,28 @@ def run_few(seed, log=print):
     return 0
 
 
-def copies_world(w, rng):
+def copies_world(w, rng, nested=False):
     """Triangles listed more than once, next to triangles of the same corners in another order (another Shape, often
-    the very same t) and the odd sphere: one to three groups, each under a transform of its own, and loose shapes --
-    the arrangements whose ids rt_device.h end_of_copy_run gets exactly (copies within one group, loose copies)."""
+    the very same t) and the odd sphere: one to three groups, each under a transform of its own, and loose shapes.
+    nested: trees of groups, most of them without a transform, that draw from ONE pool of triangles -- copies in
+    different groups under one transformed ancestor, some in groups whose box the ray misses -- some of them divided
+    (groups.rs:198-299).  (rt_device.h end_of_copy_run)"""
     import itertools
     perms = list(itertools.permutations(range(3)))
 
-    def fill(add):
+    def new_pool():
         exact = rng.randint(2) == 0  # small integers: every corner order gives the same t far more often
         pool = []
         for _ in range(int(rng.randint(1, 4))):
             c = rng.randint(-3, 4, size=(3, 3)).astype(float) if exact else rng.uniform(-3, 3, size=(3, 3))
             c[:, 2] = c[:, 2] * 0.25
             pool.append(c)
+        return pool
+
+    def fill(add, pool=None, lo=2, hi=12):
+        pool = pool or new_pool()
         smooth = rng.randint(4) == 0
-        for _ in range(int(rng.randint(2, 12))):
+        for _ in range(int(rng.randint(lo, hi))):
             if rng.randint(8) == 0:
                 add(w.shape("sphere", [("scale", *rng.uniform(0.3, 1.5, 3)), ("translate", *rng.uniform(-2, 2, 3))], None))
                 continue
@@ -299,10 +305,31 @@ def copies_world(w, rng):
             else:
                 add(w.shape("triangle", (), None, params=list(c.ravel())))
 
+    def some_ops():
+        return [("rotate-y", rng.uniform(-0.5, 0.5)), ("translate", *rng.uniform(-3, 3, 3))] if rng.randint(2) else \
+               [("translate", *(rng.randint(-6, 7, 3) * 0.5))]
+
+    if nested:
+        pool = new_pool() + new_pool()
+
+        def tree(depth):
+            g = w.group(some_ops() if rng.randint(4) == 0 else ())
+            fill(lambda sh: w.group_add_shape(g, sh), pool, 0, 7)
+            for _ in range(int(rng.randint(0, 4)) if depth < 3 else 0):
+                w.group_add_child(g, tree(depth + 1))
+            return g
+
+        for _ in range(int(rng.randint(1, 3))):
+            g = tree(0)
+            if rng.randint(3) == 0:
+                w.group_divide(g, int(rng.randint(1, 5)))
+            w.add_group(g)
+        if rng.randint(2):
+            fill(w.add_shape, pool)
+        w.add_point_light(tuple(rng.uniform(-10, 10, 3)), (1, 1, 1))
+        return
     for _ in range(int(rng.randint(1, 4))):
-        ops = [("rotate-y", rng.uniform(-0.5, 0.5)), ("translate", *rng.uniform(-3, 3, 3))] if rng.randint(2) else \
-              [("translate", *(rng.randint(-6, 7, 3) * 0.5))]
-        g = w.group(ops)
+        g = w.group(some_ops())
         fill(lambda sh: w.group_add_shape(g, sh))
         w.add_group(g)
     if rng.randint(2):
@@ -311,13 +338,13 @@ def copies_world(w, rng):
 
 
 def run_copies(seed, log=print):
-    """A copies_world frame and 4 000 random rays against the oracle."""
+    """A copies_world frame and 4 000 random rays against the oracle (odd seeds: the nested worlds)."""
     from raytracer_amd import builder as B
     from test_gpu_parity import check
     rng = np.random.RandomState(13000 + seed)
     gw, ow = host.new_world(0), oracle.new_world()
-    copies_world(gw, np.random.RandomState(seed))
-    copies_world(ow, np.random.RandomState(seed))
+    copies_world(gw, np.random.RandomState(seed), bool(seed % 2))
+    copies_world(ow, np.random.RandomState(seed), bool(seed % 2))
     eye = np.array([rng.uniform(-3, 3), rng.uniform(-3, 3), rng.choice([-9.0, 9.0])])
     if rng.randint(2):
         eye = np.round(eye)
