@@ -1219,16 +1219,18 @@ __device__ inline Ray ray_in_space_of(const Scene& sc, int xf_node, const Ray& w
 // equal in (t, Shape, u, v); the reference's Intersections is a BTreeMap built in bulk from the list sorted by t
 // (stable: insertion order within one t), and that build drops an entry that is == its SUCCESSOR.  So of
 // the entries at the hit's t, in insertion order, the hit is the last of the first run of equal neighbours: the sink's
-// winner `w` (lowest rank at that t) gives way to its next copy -- the next triangle of the same value class under the
-// same transformed ancestor, linked through the record's unused min slot by rt_scene_create -- unless some entry in
-// between has the very same t (one made of the same vertices in another order, say), or the copy is not an entry at
-// all (its group's box, or one above it, is missed by the ray).  So this walks on from w in insertion order exactly as
-// the reference gathers entries (groups depth-first, shapes before children, groups.rs:111-123, with the reference's
-// own box tests and rays; then the loose shapes, world.rs:56-59), intersects every shape it passes and stops at the
-// first with that t that is not the next copy.  What it does not look at: the leaves of a csg (a csg's entries are not
-// its leaves' -- a leaf that is a copy is taken over unseen), and anything after RT_COPY_GAP_MAX shapes (from there on
-// every further copy is taken over unseen).  Not part of the render kernels: a pass of its own over the ids
-// (rt_hip.hip k_copies_pixels / k_copies_rays), only for scenes with copies and callers that ask for ids.
+// winner `w` (lowest rank at that t) gives way to the next entry at that t if that is an equal shape with equal (u, v).
+// rt_scene_create links every triangle to the next of its value class (the record's unused min slot).  A copy is
+// first intersected by itself, with the ray of its own group: one that is not hit at that very t (nearly every copy
+// under ANOTHER transform: the instances of a mesh) is no entry there and is passed over.  One that is -- every copy
+// under the same transformed ancestor, and the odd one moved within its own plane -- is walked to, from where the walk
+// stands, in the order the reference gathers entries (groups depth-first, shapes before children, groups.rs:111-123,
+// with the reference's own box tests and rays; then the loose shapes, world.rs:56-59): every shape passed on the way
+// is intersected, and one with that t ends the run, as does a copy whose group the ray does not reach (no entry) or
+// whose (u, v) differ.  What it does not look at: the leaves of a csg (a csg's entries are not its leaves' -- a leaf
+// that is a copy of a leaf is taken over unseen), and anything after RT_COPY_GAP_MAX intersections (the run ends
+// there).  Not part of the render kernels: a pass of its own over the ids (rt_hip.hip k_copies_pixels /
+// k_copies_rays), only for scenes with copies and callers that ask for ids.
 #ifndef RT_COPY_GAP_MAX
 #define RT_COPY_GAP_MAX 65536
 #endif
@@ -1242,6 +1244,71 @@ __device__ inline int next_copy(const Scene& sc, int s) {
   const u4n w0 = cst(reinterpret_cast<const u4n*>(sc.shapes + s))[0], w1 = cst(reinterpret_cast<const u4n*>(sc.shapes + s))[1];
   return (w0.x & RT_SHAPE_KIND_MASK) >= RT_TRIANGLE ? (int)w1.z : s;
 }
+enum { RUN_BROKEN = 0, RUN_REACHED = 1, RUN_UNREACHED = 2 };
+// Where a walk stands in the reference's order of entries.
+struct OrderWalk {
+  uint32_t i;                      // the node the walk is at
+  uint32_t k;                      // inside a node: its next own shape; among the loose shapes: the next shape
+  uint32_t first_shape, n_shapes;  // of node i, when inside
+  bool inside;                     // node i was reached: its shapes from k on come next
+  bool loose;                      // the groups are done
+  int at;                          // every shape up to this index is behind the walk
+  Ray cur;                         // the ray in the space of the node the walk is at
+  uint32_t leave_at;
+  // Walks on to shape `target` (> at); every shape passed on the way is intersected: RUN_BROKEN = one of them has t0.
+  __device__ inline int advance(const Scene& sc, const Ray& world, int target, float t0, int& budget) {
+    for (;;) {
+      if (!loose && !inside) {
+        if (i >= sc.n_nodes) {
+          loose = true;
+          const int first_loose = (int)(sc.n_shapes - sc.n_loose);
+          k = (uint32_t)(first_loose > at + 1 ? first_loose : at + 1);
+          continue;
+        }
+        const u4n RT_CONST_AS* raw = cst(reinterpret_cast<const u4n*>(sc.nodes + i));
+        const u4n n0 = raw[0], n1 = raw[1], n2 = raw[2];
+        if ((int)n2.x > target) return RUN_UNREACHED;  // the target lies behind: in a subtree the ray does not enter
+        const uint32_t xform = n0.w, skip = n2.z;
+        if (i >= leave_at) {
+          const int par = (int)n2.w;
+          const int q = par >= 0 ? cst(sc.nodes)[par].next_xf : -1;
+          cur = q >= 0 ? ray_in_space_of<true>(sc, q, world) : world;
+          leave_at = q >= 0 ? cst(sc.nodes)[q].skip : 0xFFFFFFFFu;
+        }
+        if (xform) {
+          cur = xf_ray(sc, xform, cur);
+          leave_at = skip;
+        }
+        float tmin, tmax;
+        if (!slab_decided(cur, v3(__uint_as_float(n0.x), __uint_as_float(n0.y), __uint_as_float(n0.z)),
+                          v3(__uint_as_float(n1.x), __uint_as_float(n1.y), __uint_as_float(n1.z)), tmin, tmax)) {  // groups.rs:111-113
+          i = skip;
+          continue;
+        }
+        inside = true;
+        first_shape = n2.x;
+        n_shapes = n2.y;
+        k = 0;
+      }
+      const uint32_t end = loose ? sc.n_shapes : n_shapes;
+      while (k < end) {
+        const int idx = (int)(loose ? k : first_shape + k);
+        if (idx > target) return RUN_UNREACHED;
+        k++;
+        if (idx <= at) continue;
+        at = idx;
+        if (idx == target) return RUN_REACHED;
+        if (budget-- <= 0) return RUN_BROKEN;
+        SameT between{t0, false};
+        shape_intersect<false>(sc, (uint32_t)idx, loose ? world : cur, between);
+        if (between.found) return RUN_BROKEN;
+      }
+      if (loose) return RUN_UNREACHED;
+      inside = false;
+      i = i + 1u;
+    }
+  }
+};
 __device__ inline int end_of_copy_run(const Scene& sc, const Ray& world, int w) {
   int next = next_copy(sc, w);
   if (next == w) return w;
@@ -1254,78 +1321,52 @@ __device__ inline int end_of_copy_run(const Scene& sc, const Ray& world, int w) 
   if (next == w) return w;
   const u4n w0 = cst(reinterpret_cast<const u4n*>(sc.shapes + w))[0], w1 = cst(reinterpret_cast<const u4n*>(sc.shapes + w))[1];
   const int parent = (int)w0.w;
+  const bool smooth = (w0.x & RT_SHAPE_KIND_MASK) == RT_SMOOTH_TRIANGLE;
   // the ray in the space of w's group, through the same chain of transforms as the walk (same bits), and the hit's t
   const int anchor = parent >= 0 ? cst(sc.nodes)[parent].next_xf : -1;
-  Ray cur = anchor >= 0 ? ray_in_space_of<true>(sc, anchor, world) : world;
-  float t0, u, v;
+  const Ray local = anchor >= 0 ? ray_in_space_of<true>(sc, anchor, world) : world;
+  float t0, u0, v0;
   {
     V3 p1, e1, e2;
     load_tri(sc, w1.y, p1, e1, e2);
-    if (!isect_triangle(w0.y ? xf_ray(sc, w0.y, cur) : cur, p1, e1, e2, t0, u, v)) return w;
+    if (!isect_triangle(w0.y ? xf_ray(sc, w0.y, local) : local, p1, e1, e2, t0, u0, v0)) return w;
   }
+  OrderWalk walk;
+  walk.at = w;
+  walk.cur = local;
+  walk.leave_at = anchor >= 0 ? cst(sc.nodes)[anchor].skip : 0xFFFFFFFFu;
+  walk.loose = parent < 0 && w >= first_loose;
+  walk.inside = parent >= 0;  // w's own group: the ray got there, and `local` is the ray it was given
+  walk.i = parent >= 0 ? (uint32_t)parent : 0u;
+  walk.first_shape = parent >= 0 ? cst(sc.nodes)[parent].first_shape : 0u;
+  walk.n_shapes = parent >= 0 ? cst(sc.nodes)[parent].n_shapes : 0u;
+  walk.k = walk.loose ? (uint32_t)(w + 1) : parent >= 0 ? (uint32_t)w + 1u - walk.first_shape : 0u;
   int budget = RT_COPY_GAP_MAX;
-  // one shape of the order: 0 = go on, 1 = the run ends at w
-  auto pass = [&](int k, const Ray& r) -> int {
-    if (k <= w) return 0;
-    if (k == next) {  // the next copy is an entry and nothing at t0 lies between: the run goes on
-      w = next;
-      next = next_copy(sc, w);
-      return next == w ? 1 : 0;
+  while (next != w) {
+    const int c = next;
+    next = next_copy(sc, c);
+    const bool last = next == c;
+    // is the copy hit at t0 at all, by the ray of its own group?
+    const u4n c0 = cst(reinterpret_cast<const u4n*>(sc.shapes + c))[0], c1 = cst(reinterpret_cast<const u4n*>(sc.shapes + c))[1];
+    const int c_parent = (int)c0.w;
+    const int c_anchor = c_parent >= 0 ? cst(sc.nodes)[c_parent].next_xf : -1;
+    const Ray rc = c_anchor == anchor ? local : c_anchor >= 0 ? ray_in_space_of<true>(sc, c_anchor, world) : world;
+    float tc, uc, vc;
+    V3 p1, e1, e2;
+    load_tri(sc, c1.y, p1, e1, e2);
+    if (budget-- <= 0) break;
+    bool entry = isect_triangle(c0.y ? xf_ray(sc, c0.y, rc) : rc, p1, e1, e2, tc, uc, vc) && of_eq(tc, t0);
+    if (entry) {
+      const int r = walk.advance(sc, world, c, t0, budget);
+      if (r == RUN_BROKEN) break;
+      entry = r == RUN_REACHED;
     }
-    if (budget-- <= 0) return 0;
-    SameT between{t0, false};
-    shape_intersect<false>(sc, (uint32_t)k, r, between);
-    return between.found ? 1 : 0;
-  };
-  // a copy that the order has passed without meeting it is not an entry (its group was not reached): on to the one after
-  auto passed = [&](int upto) -> int {  // every shape below `upto` is behind us; 1 = no copy is left
-    while (next < upto) {
-      const int n2 = next_copy(sc, next);
-      if (n2 == next) return 1;
-      next = n2;
+    if (entry) {
+      if (smooth && !(uc == u0 && vc == v0)) break;  // an entry at t0 that is not equal: the run ends before it
+      w = c;
     }
-    return 0;
-  };
-  if (parent >= 0 || w < first_loose) {
-    uint32_t leave_at = anchor >= 0 ? cst(sc.nodes)[anchor].skip : 0xFFFFFFFFu;
-    uint32_t i = parent >= 0 ? (uint32_t)parent : 0u;
-    bool reached = parent >= 0;  // w's own group: the ray got there, and `cur` is the ray it was given
-    const uint32_t end = anchor >= 0 ? cst(sc.nodes)[anchor].skip : sc.n_nodes;  // copies share the transformed ancestor
-    while (i < end) {
-      const u4n RT_CONST_AS* raw = cst(reinterpret_cast<const u4n*>(sc.nodes + i));
-      const u4n n0 = raw[0], n1 = raw[1], n2 = raw[2];
-      const uint32_t xform = n0.w, first_shape = n2.x, n_shapes = n2.y, skip = n2.z;
-      if (passed((int)first_shape)) return w;
-      bool descend = reached;
-      if (!reached) {
-        if (i >= leave_at) {
-          const int par = (int)n2.w;
-          const int q = par >= 0 ? cst(sc.nodes)[par].next_xf : -1;
-          cur = q >= 0 ? ray_in_space_of<true>(sc, q, world) : world;
-          leave_at = q >= 0 ? cst(sc.nodes)[q].skip : 0xFFFFFFFFu;
-        }
-        if (xform) {
-          cur = xf_ray(sc, xform, cur);
-          leave_at = skip;
-        }
-        float tmin, tmax;
-        descend = slab_decided(cur, v3(__uint_as_float(n0.x), __uint_as_float(n0.y), __uint_as_float(n0.z)),
-                               v3(__uint_as_float(n1.x), __uint_as_float(n1.y), __uint_as_float(n1.z)), tmin, tmax);  // groups.rs:111-113
-      }
-      reached = false;
-      if (descend) {
-        for (uint32_t k = 0; k < n_shapes; k++)
-          if (pass((int)(first_shape + k), cur)) return w;
-        i = i + 1u;
-      } else {
-        i = skip;
-      }
-    }
-    if (anchor >= 0) return w;  // (every copy is below the ancestor: whatever is left was not reached)
+    if (last) break;
   }
-  if (passed(first_loose)) return w;
-  for (int k = first_loose > w ? first_loose : w + 1; k < (int)sc.n_shapes; k++)
-    if (pass(k, world)) return w;
   return w;
 }
 

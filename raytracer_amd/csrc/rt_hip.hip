@@ -1034,12 +1034,9 @@ int rt_scene_create(RtContext* ctx, const RtScene* s, RtDeviceScene** out) {
       // Which of several value-identical triangles is reported as hit (rt_device.h end_of_copy_run). A mesh that lists
       // a triangle twice gives two entries equal in (t, Shape, u, v), and of such neighbours the reference's
       // Intersections keeps the LATER one (BTreeMap bulk build), whereas ties between different shapes
-      // go to the earlier. Duplicates are the same class under the same transformed ancestor; the device copy of a
-      // triangle holds the NEXT of them in the unused `mn` slot (itself: none).  Duplicates that sit in DIFFERENT groups
-      // are linked too: exact whenever the ray that hits both also passes both groups' box tests, which holds for every mesh
-      // `divide` builds (equal triangles have equal boxes and take the same side at every split); for hand-placed
-      // duplicates in groups with different boxes a ray within rounding of one box's face may report the other id
-      // (the id only: the shapes are equal, so is the colour).
+      // go to the earlier. The device copy of a triangle holds the NEXT triangle of its value class, wherever it
+      // sits, in the unused `mn` slot (itself: none); whether that one is an entry at the same t for a given ray --
+      // always, under the same transformed ancestor; hardly ever, under another -- is decided on the device.
       // only classes that occur more than once can have duplicates: count first (one pass), sort the few that remain
       uint32_t max_class = 0;
       for (uint32_t m : piece_max) max_class = std::max(max_class, m);
@@ -1057,9 +1054,7 @@ int rt_scene_create(RtContext* ctx, const RtScene* s, RtDeviceScene** out) {
         for (uint32_t i = b; i < e; i++)
           if ((shapes[i].kind_flags & RT_SHAPE_KIND_MASK) >= RT_TRIANGLE && shapes[i].vclass != RT_VCLASS_NEVER &&
               seen[shapes[i].vclass] >= 2) {
-            const int32_t par = shapes[i].parent;
-            const int64_t anchor = par >= 0 ? (int64_t)s->nodes[par].next_xf + 1 : 0;
-            piece_keyed[piece].emplace_back(((uint64_t)shapes[i].vclass << 32) | (uint64_t)anchor, i);
+            piece_keyed[piece].emplace_back((uint64_t)shapes[i].vclass, i);
           }
       });
       std::vector<std::pair<uint64_t, uint32_t>> keyed;

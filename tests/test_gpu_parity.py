@@ -995,6 +995,9 @@ def test_a_coincident_triangle_between_two_copies_of_a_triangle(order, expected,
     (("a", [("s",), ("a",)]), 2),             # ... with another group's sphere between them, met elsewhere
     (("aa", [("xa",)]), 1),
     (("", [("a", [("a",)]), ("a",), ("xa",)]), 2),
+    (("a", [("a", [], "moved")]), 1),         # an equal shape under ANOTHER transform, moved within its own plane: same t
+    (("a", [("x", [], "moved"), ("a",)]), 0),
+    (("a", [("a", [], "moved"), ("x",), ("a", [], "moved"), ("a",)]), 1),
 ])
 def test_copies_of_a_triangle_in_different_groups(tree, expected):
     """Copies in different groups under one transformed ancestor are neighbours in the reference's list like any

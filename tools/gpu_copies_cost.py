@@ -19,3 +19,19 @@ for k in range(4):
     r = w.render(cam, aux=True)
 ids = r.object_id
 print("triangles per mesh", len(g["vidx"]), "pixels hit", int((ids >= 0).sum()), "frame ms", r.stats.get("kernel_ms"), flush=True)
+
+# second case: six instances of one mesh with ONE material (every triangle has five equal shapes under other
+# transforms: each is intersected once per hit, none is an entry at the hit's t)
+from raytracer_amd import builder as B
+mesh = synth.synth_dragon()[0]
+w2 = host.new_world(0)
+for k in range(6):
+    g = w2.group([("scale", 0.25, 0.25, 0.25), ("translate", (k % 3 - 1) * 2.2, (k // 3) * 1.6 - 0.8, 0.0)])
+    w2.group_add_mesh(g, B.Material(color=(0.8, 0.3, 0.2)), mesh["positions"], mesh["normals"], mesh["vidx"], mesh["nidx"])
+    w2.group_divide(g, 100)
+    w2.add_group(g)
+w2.add_point_light((-5, 8, -10), (1, 1, 1))
+cam2 = B.Camera(3840, 2160, 0.9, (0, 0.5, -7), (0, 0, 0), (0, 1, 0))
+for k in range(4):
+    r2 = w2.render(cam2, aux=True)
+print("six instances of one material: pixels hit", int((r2.object_id >= 0).sum()), flush=True)

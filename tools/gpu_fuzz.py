@@ -312,8 +312,11 @@ def copies_world(w, rng, nested=False):
     if nested:
         pool = new_pool() + new_pool()
 
+        def in_plane():  # equal shapes under different transforms, hit at the same t more often than not
+            return [("translate", float(rng.randint(-4, 5)) * 0.5, float(rng.randint(-4, 5)) * 0.5, 0.0)]
+
         def tree(depth):
-            g = w.group(some_ops() if rng.randint(4) == 0 else ())
+            g = w.group((in_plane() if rng.randint(2) else some_ops()) if rng.randint(3) == 0 else ())
             fill(lambda sh: w.group_add_shape(g, sh), pool, 0, 7)
             for _ in range(int(rng.randint(0, 4)) if depth < 3 else 0):
                 w.group_add_child(g, tree(depth + 1))
