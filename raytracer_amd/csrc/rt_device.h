@@ -1227,10 +1227,10 @@ __device__ inline Ray ray_in_space_of(const Scene& sc, int xf_node, const Ray& w
 // stands, in the order the reference gathers entries (groups depth-first, shapes before children, groups.rs:111-123,
 // with the reference's own box tests and rays; then the loose shapes, world.rs:56-59): every shape passed on the way
 // is intersected, and one with that t ends the run, as does a copy whose group the ray does not reach (no entry) or
-// whose (u, v) differ.  What it does not look at: the leaves of a csg (a csg's entries are not its leaves' -- a leaf
-// that is a copy of a leaf is taken over unseen), and anything after RT_COPY_GAP_MAX intersections (the run ends
-// there).  Not part of the render kernels: a pass of its own over the ids (rt_hip.hip k_copies_pixels /
-// k_copies_rays), only for scenes with copies and callers that ask for ids.
+// whose (u, v) differ.  The csgs of the world come first in that order (world.rs:45-49): the entries of a csg are what
+// csg_eval leaves of its leaves' intersections, so a leaf is an entry only if the evaluated list holds it.  After
+// RT_COPY_GAP_MAX intersections the run ends where it stands.  Not part of the render kernels: a pass of its own over
+// the ids (rt_hip.hip k_copies_pixels / k_copies_rays), only for scenes with copies and callers that ask for ids.
 #ifndef RT_COPY_GAP_MAX
 #define RT_COPY_GAP_MAX 65536
 #endif
@@ -1247,6 +1247,8 @@ __device__ inline int next_copy(const Scene& sc, int s) {
 enum { RUN_BROKEN = 0, RUN_REACHED = 1, RUN_UNREACHED = 2 };
 // Where a walk stands in the reference's order of entries.
 struct OrderWalk {
+  bool csg;                        // the walk is among the csgs
+  uint32_t root;                   // ... at this one
   uint32_t i;                      // the node the walk is at
   uint32_t k;                      // inside a node: its next own shape; among the loose shapes: the next shape
   uint32_t first_shape, n_shapes;  // of node i, when inside
@@ -1257,6 +1259,22 @@ struct OrderWalk {
   uint32_t leave_at;
   // Walks on to shape `target` (> at); every shape passed on the way is intersected: RUN_BROKEN = one of them has t0.
   __device__ inline int advance(const Scene& sc, const Ray& world, int target, float t0, int& budget) {
+    if (csg) {
+      CsgListT<true> L;
+      L.overflow = 0;
+      for (; root < sc.n_csg_roots; root++) {
+        if ((budget -= 8) <= 0) return RUN_BROKEN;
+        csg_eval<true>(sc, sc.csg_roots[root], world, L);
+        int first = 0x7FFFFFFF;  // the next entry at t0 in this csg's list
+        for (int e = 0; e < L.n; e++)
+          if (of_eq(L.t[e], t0) && (int)L.s[e] > at && (int)L.s[e] < first) first = (int)L.s[e];
+        if (first == 0x7FFFFFFF) continue;
+        if (first > target) return RUN_UNREACHED;  // (the leaves of a csg are a range of their own: the target is not in its list)
+        at = first;
+        return first == target ? RUN_REACHED : RUN_BROKEN;
+      }
+      csg = false;
+    }
     for (;;) {
       if (!loose && !inside) {
         if (i >= sc.n_nodes) {
@@ -1313,12 +1331,6 @@ __device__ inline int end_of_copy_run(const Scene& sc, const Ray& world, int w) 
   int next = next_copy(sc, w);
   if (next == w) return w;
   const int first_loose = (int)(sc.n_shapes - sc.n_loose);
-  // leaves of a csg come first in the order: copies among them are taken over unseen
-  while (next != w && cst(sc.shapes)[w].parent < 0 && w < first_loose && cst(sc.shapes)[next].parent < 0 && next < first_loose) {
-    w = next;
-    next = next_copy(sc, w);
-  }
-  if (next == w) return w;
   const u4n w0 = cst(reinterpret_cast<const u4n*>(sc.shapes + w))[0], w1 = cst(reinterpret_cast<const u4n*>(sc.shapes + w))[1];
   const int parent = (int)w0.w;
   const bool smooth = (w0.x & RT_SHAPE_KIND_MASK) == RT_SMOOTH_TRIANGLE;
@@ -1335,6 +1347,8 @@ __device__ inline int end_of_copy_run(const Scene& sc, const Ray& world, int w) 
   walk.at = w;
   walk.cur = local;
   walk.leave_at = anchor >= 0 ? cst(sc.nodes)[anchor].skip : 0xFFFFFFFFu;
+  walk.csg = parent < 0 && w < first_loose;  // the leaf of a csg
+  walk.root = 0u;
   walk.loose = parent < 0 && w >= first_loose;
   walk.inside = parent >= 0;  // w's own group: the ray got there, and `local` is the ray it was given
   walk.i = parent >= 0 ? (uint32_t)parent : 0u;

@@ -1029,6 +1029,35 @@ def test_copies_of_a_triangle_in_different_groups(tree, expected):
     check(build(host.new_world(0)).render(cam, aux=True), build(_oracle().new_world()).render(cam, aux=True), f"copies {tree}")
 
 
+@pytest.mark.parametrize("leaves,loose,expected", [("as", "a", 2), ("ax", "a", 2), ("aa", "a", 2), ("sa", "xa", 1),
+                                                   ("xa", "a", 0), ("as", "xa", 0)])
+def test_copies_of_a_triangle_in_a_csg(leaves, loose, expected):
+    """The entries of a csg are what its evaluation leaves of its leaves' intersections (csg.rs:26-72), first in the
+    world's list (world.rs:45-49): a leaf that is a copy of a later triangle is its neighbour like any other entry.
+    A union of two leaves, then loose triangles; s: a sphere met elsewhere.  (ax + a: the union drops the right leaf's x,
+    met inside the left leaf at the same t, so the two a are neighbours.)"""
+    def shape(w, c):
+        if c == "s":
+            return w.shape("sphere", [("translate", 1, 1, -3)], None)
+        return w.shape("triangle", (), None, params=_COPY_A if c == "a" else _COPY_X)
+
+    def build(w):
+        w.add_csg(w.csg(B.CSG_UNION, B.CHILD_SHAPE, shape(w, leaves[0]), B.CHILD_SHAPE, shape(w, leaves[1])))
+        for c in loose:
+            w.add_shape(shape(w, c))
+        w.add_point_light((0, 5, 10), (1, 1, 1))
+        return w
+
+    o = np.array([[1.5, 1.5, 5.0]], dtype=np.float32)
+    d = np.array([[0.0, 0.0, -1.0]], dtype=np.float32)
+    _, gt, gid, _ = build(host.new_world(0)).color_at(o, d, 0)
+    _, rt_, rid, _ = build(_oracle().new_world()).color_at(o, d, 0)
+    assert gt[0] == rt_[0] == 5.0
+    assert rid[0] == expected and gid[0] == rid[0]
+    cam = B.Camera(48, 32, 0.9, (1.2, 1.1, 6.0), (1.2, 1.1, 0.0), (0, 1, 0))
+    check(build(host.new_world(0)).render(cam, aux=True), build(_oracle().new_world()).render(cam, aux=True), f"csg copies {leaves} {loose}")
+
+
 def test_copies_of_a_triangle_in_parts():
     """The pass over the ids (k_copies_pixels) finds a pixel's ray from its row in the PART: interleaved parts of a
     frame whose every pixel needs the pass give the ids of the whole frame, which are the oracle's."""

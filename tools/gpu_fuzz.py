@@ -329,6 +329,16 @@ def copies_world(w, rng, nested=False):
             w.add_group(g)
         if rng.randint(2):
             fill(w.add_shape, pool)
+        for _ in range(int(rng.randint(0, 3)) if rng.randint(2) else 0):  # csgs whose leaves come from the same pool
+            from raytracer_amd import builder as B
+            leaves = []
+            fill(leaves.append, pool, 3, 4)
+            ops = [B.CSG_UNION, B.CSG_INTERSECT, B.CSG_DIFFERENCE]
+            c = w.csg(int(rng.choice(ops)), B.CHILD_SHAPE, leaves[0], B.CHILD_SHAPE, leaves[1])
+            if rng.randint(2):
+                c = w.csg(int(rng.choice(ops)), B.CHILD_CSG, c, B.CHILD_SHAPE, leaves[2]) if rng.randint(2) else \
+                    w.csg(int(rng.choice(ops)), B.CHILD_SHAPE, leaves[2], B.CHILD_CSG, c)
+            w.add_csg(c)
         w.add_point_light(tuple(rng.uniform(-10, 10, 3)), (1, 1, 1))
         return
     for _ in range(int(rng.randint(1, 4))):
