@@ -1037,35 +1037,32 @@ int rt_scene_create(RtContext* ctx, const RtScene* s, RtDeviceScene** out) {
       // go to the earlier. The device copy of a triangle holds the NEXT triangle of its value class, wherever it
       // sits, in the unused `mn` slot (itself: none); whether that one is an entry at the same t for a given ray --
       // always, under the same transformed ancestor; hardly ever, under another -- is decided on the device.
-      // only classes that occur more than once can have duplicates: count first (one pass), sort the few that remain
+      // only classes that occur more than once can have duplicates: count first (one pass on threads); only then the
+      // links, in one pass from the last shape to the first (per class: the index met last, i.e. the next one)
       uint32_t max_class = 0;
       for (uint32_t m : piece_max) max_class = std::max(max_class, m);
       std::vector<uint8_t> seen((size_t)max_class + 1, 0);  // per class: 1 = seen once, 2 and more = more than once
-      in_pieces([&](uint32_t, uint32_t b, uint32_t e) {
+      std::vector<uint8_t> piece_dup(n_pieces, 0);
+      in_pieces([&](uint32_t piece, uint32_t b, uint32_t e) {
         for (uint32_t i = b; i < e; i++)
           // a triangle that holds a NaN equals no shape, itself included: it is nobody's duplicate
           // (a count stops being raised once somebody sees 2: with one thread per piece it stays below 2 + their number)
           if ((shapes[i].kind_flags & RT_SHAPE_KIND_MASK) >= RT_TRIANGLE && shapes[i].vclass != RT_VCLASS_NEVER &&
-              __atomic_load_n(&seen[shapes[i].vclass], __ATOMIC_RELAXED) < 2)
-            __atomic_fetch_add(&seen[shapes[i].vclass], (uint8_t)1, __ATOMIC_RELAXED);
+              __atomic_load_n(&seen[shapes[i].vclass], __ATOMIC_RELAXED) < 2 &&
+              __atomic_fetch_add(&seen[shapes[i].vclass], (uint8_t)1, __ATOMIC_RELAXED) >= 1)
+            piece_dup[piece] = 1;
       });
-      std::vector<std::vector<std::pair<uint64_t, uint32_t>>> piece_keyed(n_pieces);
-      in_pieces([&](uint32_t piece, uint32_t b, uint32_t e) {
-        for (uint32_t i = b; i < e; i++)
-          if ((shapes[i].kind_flags & RT_SHAPE_KIND_MASK) >= RT_TRIANGLE && shapes[i].vclass != RT_VCLASS_NEVER &&
-              seen[shapes[i].vclass] >= 2) {
-            piece_keyed[piece].emplace_back((uint64_t)shapes[i].vclass, i);
-          }
-      });
-      std::vector<std::pair<uint64_t, uint32_t>> keyed;
-      for (auto& list : piece_keyed) keyed.insert(keyed.end(), list.begin(), list.end());
-      std::sort(keyed.begin(), keyed.end());
-      for (size_t a = 0; a < keyed.size();) {
-        size_t b = a + 1;
-        while (b < keyed.size() && keyed[b].first == keyed[a].first) b++;
-        for (size_t k = a; k + 1 < b; k++) memcpy(&shapes[keyed[k].second].mn, &keyed[k + 1].second, sizeof(uint32_t));
-        if (b - a > 1) d.props |= RT_SCENE_HAS_COPIES;
-        a = b;
+      if (std::find(piece_dup.begin(), piece_dup.end(), (uint8_t)1) != piece_dup.end()) {
+        d.props |= RT_SCENE_HAS_COPIES;
+        std::vector<uint32_t> later((size_t)max_class + 1, 0xFFFFFFFFu);
+        for (uint32_t i = s->n_shapes; i-- > 0;) {
+          if ((shapes[i].kind_flags & RT_SHAPE_KIND_MASK) < RT_TRIANGLE || shapes[i].vclass == RT_VCLASS_NEVER ||
+              seen[shapes[i].vclass] < 2)
+            continue;
+          uint32_t& l = later[shapes[i].vclass];
+          if (l != 0xFFFFFFFFu) memcpy(&shapes[i].mn, &l, sizeof(uint32_t));
+          l = i;
+        }
       }
     }
     stage("cull records, duplicate links");
