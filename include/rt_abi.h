@@ -223,7 +223,7 @@ typedef struct {
 /* Optional per-pixel side outputs of the PRIMARY ray, same compaction as the image. */
 typedef struct {
   uint8_t* hit_mask;  /* 1 = hit */
-  int32_t* object_id; /* shape index (insertion rank) or -1; of equal triangles met at one t, the one the reference's
+  int32_t* object_id; /* shape index (insertion rank) or -1; of equal shapes met at one t, the one the reference's
                          Intersections keeps (src/intersections.rs:66-73: the last of the first run of equal neighbours) */
   float* hit_t;
 } RtAux;

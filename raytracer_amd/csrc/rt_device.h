@@ -1215,12 +1215,12 @@ __device__ inline Ray ray_in_space_of(const Scene& sc, int xf_node, const Ray& w
   for (int k = n - 1; k >= 0; k--) r = xf_ray(sc, cst(sc.nodes)[chain[k]].xform, r);
   return r;
 }
-// Which of several value-identical triangles a hit is booked on.  A mesh that lists a triangle twice gives two entries
+// Which of several value-identical shapes a hit is booked on.  A mesh that lists a triangle twice gives two entries
 // equal in (t, Shape, u, v); the reference's Intersections is a BTreeMap built in bulk from the list sorted by t
 // (stable: insertion order within one t), and that build drops an entry that is == its SUCCESSOR.  So of
 // the entries at the hit's t, in insertion order, the hit is the last of the first run of equal neighbours: the sink's
 // winner `w` (lowest rank at that t) gives way to the next entry at that t if that is an equal shape with equal (u, v).
-// rt_scene_create links every triangle to the next of its value class (the record's unused min slot).  A copy is
+// rt_scene_create links every shape to the next of its value class (a slot its kind does not use).  A copy is
 // first intersected by itself, with the ray of its own group: one that is not hit at that very t (nearly every copy
 // under ANOTHER transform: the instances of a mesh) is no entry there and is passed over.  One that is -- every copy
 // under the same transformed ancestor, and the odd one moved within its own plane -- is walked to, from where the walk
@@ -1240,10 +1240,30 @@ struct SameT {
   __device__ __forceinline__ bool takes(uint32_t) const { return true; }
   __device__ __forceinline__ void add(float tt, uint32_t, float, float) { found = found || of_eq(tt, t0); }
 };
+// (the link sits in a slot of the record that the shape's kind does not use: the min of everything but cylinders and
+// cones, whose slot is the triangle index)
 __device__ inline int next_copy(const Scene& sc, int s) {
   const u4n w0 = cst(reinterpret_cast<const u4n*>(sc.shapes + s))[0], w1 = cst(reinterpret_cast<const u4n*>(sc.shapes + s))[1];
-  return (w0.x & RT_SHAPE_KIND_MASK) >= RT_TRIANGLE ? (int)w1.z : s;
+  const uint32_t kind = w0.x & RT_SHAPE_KIND_MASK;
+  return (int)(kind == RT_CYLINDER || kind == RT_CONE ? w1.y : w1.z);
 }
+// A shape's own entries: the nearest in front of the origin (the hit, when the shape is the one hit) ...
+struct OwnHit {
+  float t, u, v;
+  __device__ __forceinline__ bool takes(uint32_t) const { return true; }
+  __device__ __forceinline__ void add(float tt, uint32_t, float uu, float vv) {
+    if (tt > 0.f && tt < t) t = tt, u = uu, v = vv;
+  }
+};
+// ... and whether one of them is at t0 (with its (u, v))
+struct EntryAt {
+  float t0, u, v;
+  bool found;
+  __device__ __forceinline__ bool takes(uint32_t) const { return true; }
+  __device__ __forceinline__ void add(float tt, uint32_t, float uu, float vv) {
+    if (!found && of_eq(tt, t0)) found = true, u = uu, v = vv;
+  }
+};
 enum { RUN_BROKEN = 0, RUN_REACHED = 1, RUN_UNREACHED = 2 };
 // Where a walk stands in the reference's order of entries.
 struct OrderWalk {
@@ -1331,18 +1351,16 @@ __device__ inline int end_of_copy_run(const Scene& sc, const Ray& world, int w) 
   int next = next_copy(sc, w);
   if (next == w) return w;
   const int first_loose = (int)(sc.n_shapes - sc.n_loose);
-  const u4n w0 = cst(reinterpret_cast<const u4n*>(sc.shapes + w))[0], w1 = cst(reinterpret_cast<const u4n*>(sc.shapes + w))[1];
+  const u4n w0 = cst(reinterpret_cast<const u4n*>(sc.shapes + w))[0];
   const int parent = (int)w0.w;
   const bool smooth = (w0.x & RT_SHAPE_KIND_MASK) == RT_SMOOTH_TRIANGLE;
   // the ray in the space of w's group, through the same chain of transforms as the walk (same bits), and the hit's t
   const int anchor = parent >= 0 ? cst(sc.nodes)[parent].next_xf : -1;
   const Ray local = anchor >= 0 ? ray_in_space_of<true>(sc, anchor, world) : world;
-  float t0, u0, v0;
-  {
-    V3 p1, e1, e2;
-    load_tri(sc, w1.y, p1, e1, e2);
-    if (!isect_triangle(w0.y ? xf_ray(sc, w0.y, local) : local, p1, e1, e2, t0, u0, v0)) return w;
-  }
+  OwnHit own{__builtin_inff(), 0.f, 0.f};
+  shape_intersect<false>(sc, (uint32_t)w, local, own);
+  if (!(own.t < __builtin_inff())) return w;  // (a hit at t = +inf is nobody's neighbour worth the search)
+  const float t0 = own.t, u0 = own.u, v0 = own.v;
   OrderWalk walk;
   walk.at = w;
   walk.cur = local;
@@ -1361,22 +1379,20 @@ __device__ inline int end_of_copy_run(const Scene& sc, const Ray& world, int w) 
     next = next_copy(sc, c);
     const bool last = next == c;
     // is the copy hit at t0 at all, by the ray of its own group?
-    const u4n c0 = cst(reinterpret_cast<const u4n*>(sc.shapes + c))[0], c1 = cst(reinterpret_cast<const u4n*>(sc.shapes + c))[1];
-    const int c_parent = (int)c0.w;
+    const int c_parent = cst(sc.shapes)[c].parent;
     const int c_anchor = c_parent >= 0 ? cst(sc.nodes)[c_parent].next_xf : -1;
     const Ray rc = c_anchor == anchor ? local : c_anchor >= 0 ? ray_in_space_of<true>(sc, c_anchor, world) : world;
-    float tc, uc, vc;
-    V3 p1, e1, e2;
-    load_tri(sc, c1.y, p1, e1, e2);
     if (budget-- <= 0) break;
-    bool entry = isect_triangle(c0.y ? xf_ray(sc, c0.y, rc) : rc, p1, e1, e2, tc, uc, vc) && of_eq(tc, t0);
+    EntryAt ec{t0, 0.f, 0.f, false};
+    shape_intersect<false>(sc, (uint32_t)c, rc, ec);
+    bool entry = ec.found;
     if (entry) {
       const int r = walk.advance(sc, world, c, t0, budget);
       if (r == RUN_BROKEN) break;
       entry = r == RUN_REACHED;
     }
     if (entry) {
-      if (smooth && !(uc == u0 && vc == v0)) break;  // an entry at t0 that is not equal: the run ends before it
+      if (smooth && !(ec.u == u0 && ec.v == v0)) break;  // an entry at t0 that is not equal: the run ends before it
       w = c;
     }
     if (last) break;

@@ -1011,9 +1011,9 @@ int rt_scene_create(RtContext* ctx, const RtScene* s, RtDeviceScene** out) {
         for (uint32_t i = b; i < e; i++) {
           shapes[i] = s->shapes[i];
           const uint32_t kind = shapes[i].kind_flags & RT_SHAPE_KIND_MASK;
-          if (kind >= RT_TRIANGLE) {
-            memcpy(&shapes[i].mn, &i, sizeof(uint32_t));  // next_copy: itself, until a later duplicate is found
-          } else if (kind == RT_CUBE || kind == RT_SPHERE) {
+          // next_copy: itself, until a later duplicate is found (in a slot the kind does not use)
+          memcpy(kind == RT_CYLINDER || kind == RT_CONE ? (void*)&shapes[i].prim : (void*)&shapes[i].mn, &i, sizeof(uint32_t));
+          if (kind == RT_CUBE || kind == RT_SPHERE) {
             const int32_t par = shapes[i].parent;
             const uint32_t siblings = par >= 0 ? s->nodes[par].n_shapes : s->n_loose_shapes;
             if (siblings >= RT_CULL_MIN_SHAPES) candidates[piece].push_back(i);
@@ -1031,11 +1031,11 @@ int rt_scene_create(RtContext* ctx, const RtScene* s, RtDeviceScene** out) {
             cull.insert(cull.end(), rec, rec + 12);
           }
         }
-      // Which of several value-identical triangles is reported as hit (rt_device.h end_of_copy_run). A mesh that lists
+      // Which of several value-identical shapes is reported as hit (rt_device.h end_of_copy_run). A mesh that lists
       // a triangle twice gives two entries equal in (t, Shape, u, v), and of such neighbours the reference's
       // Intersections keeps the LATER one (BTreeMap bulk build), whereas ties between different shapes
-      // go to the earlier. The device copy of a triangle holds the NEXT triangle of its value class, wherever it
-      // sits, in the unused `mn` slot (itself: none); whether that one is an entry at the same t for a given ray --
+      // go to the earlier. The device copy of a shape holds the NEXT shape of its value class, wherever it
+      // sits, in a slot its kind does not use (itself: none); whether that one is an entry at the same t for a given ray --
       // always, under the same transformed ancestor; hardly ever, under another -- is decided on the device.
       // only classes that occur more than once can have duplicates: count first (one pass on threads); only then the
       // links, in one pass from the last shape to the first (per class: the index met last, i.e. the next one)
@@ -1045,10 +1045,9 @@ int rt_scene_create(RtContext* ctx, const RtScene* s, RtDeviceScene** out) {
       std::vector<uint8_t> piece_dup(n_pieces, 0);
       in_pieces([&](uint32_t piece, uint32_t b, uint32_t e) {
         for (uint32_t i = b; i < e; i++)
-          // a triangle that holds a NaN equals no shape, itself included: it is nobody's duplicate
+          // a shape that holds a NaN equals no shape, itself included: it is nobody's duplicate
           // (a count stops being raised once somebody sees 2: with one thread per piece it stays below 2 + their number)
-          if ((shapes[i].kind_flags & RT_SHAPE_KIND_MASK) >= RT_TRIANGLE && shapes[i].vclass != RT_VCLASS_NEVER &&
-              __atomic_load_n(&seen[shapes[i].vclass], __ATOMIC_RELAXED) < 2 &&
+          if (shapes[i].vclass != RT_VCLASS_NEVER && __atomic_load_n(&seen[shapes[i].vclass], __ATOMIC_RELAXED) < 2 &&
               __atomic_fetch_add(&seen[shapes[i].vclass], (uint8_t)1, __ATOMIC_RELAXED) >= 1)
             piece_dup[piece] = 1;
       });
@@ -1056,11 +1055,11 @@ int rt_scene_create(RtContext* ctx, const RtScene* s, RtDeviceScene** out) {
         d.props |= RT_SCENE_HAS_COPIES;
         std::vector<uint32_t> later((size_t)max_class + 1, 0xFFFFFFFFu);
         for (uint32_t i = s->n_shapes; i-- > 0;) {
-          if ((shapes[i].kind_flags & RT_SHAPE_KIND_MASK) < RT_TRIANGLE || shapes[i].vclass == RT_VCLASS_NEVER ||
-              seen[shapes[i].vclass] < 2)
-            continue;
+          if (shapes[i].vclass == RT_VCLASS_NEVER || seen[shapes[i].vclass] < 2) continue;
           uint32_t& l = later[shapes[i].vclass];
-          if (l != 0xFFFFFFFFu) memcpy(&shapes[i].mn, &l, sizeof(uint32_t));
+          const uint32_t kind = shapes[i].kind_flags & RT_SHAPE_KIND_MASK;
+          if (l != 0xFFFFFFFFu)
+            memcpy(kind == RT_CYLINDER || kind == RT_CONE ? (void*)&shapes[i].prim : (void*)&shapes[i].mn, &l, sizeof(uint32_t));
           l = i;
         }
       }

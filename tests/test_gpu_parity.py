@@ -1058,6 +1058,39 @@ def test_copies_of_a_triangle_in_a_csg(leaves, loose, expected):
     check(build(host.new_world(0)).render(cam, aux=True), build(_oracle().new_world()).render(cam, aux=True), f"csg copies {leaves} {loose}")
 
 
+@pytest.mark.parametrize("kind", ["sphere", "cube", "cylinder", "cone", "plane"])
+@pytest.mark.parametrize("order,expected", [("aaa", 2), ("aba", 0), ("aab", 1), ("baa", 0), ("abaa", 0), ("aabaa", 1)])
+@pytest.mark.parametrize("grouped", [False, True])
+def test_equal_solids_listed_more_than_once(kind, order, expected, grouped):
+    """The run of equal neighbours is a rule for every kind of shape: a sphere listed three times reports the third, and
+    a sphere of another material in the same place (b: another Shape, the same t) between two of them keeps them apart."""
+    params = [-1.0, 1.0, 1.0] if kind in ("cylinder", "cone") else None
+
+    def build(w):
+        shapes = [w.shape(kind, [("translate", 0, 0.25, 0)], B.Material(color=(1, 0.2, 0.2) if c == "a" else (0.2, 1, 0.2)),
+                          params=params) for c in order]
+        if grouped:
+            g = w.group([("translate", 0.5, 0, 0)])
+            for sh in shapes:
+                w.group_add_shape(g, sh)
+            w.add_group(g)
+        else:
+            for sh in shapes:
+                w.add_shape(sh)
+        w.add_point_light((0, 5, -10), (1, 1, 1))
+        return w
+
+    x = 0.6 if grouped else 0.1
+    o = np.array([[x, 0.5, -5.0], [x + 0.2, 0.3, -5.0]], dtype=np.float32)
+    d = np.array([[0, -0.25 if kind == "plane" else 0.0, 1.0]] * 2, dtype=np.float32)
+    _, gt, gid, _ = build(host.new_world(0)).color_at(o, d, 0)
+    _, rt_, rid, _ = build(_oracle().new_world()).color_at(o, d, 0)
+    assert np.array_equal(gt.view(np.uint32), rt_.view(np.uint32)) and (rid >= 0).any()
+    assert all(r in (-1, expected) for r in rid) and np.array_equal(gid, rid)
+    cam = B.Camera(40, 30, 0.9, (0.3, 1.0, -6.0), (0.3, 0.2, 0.0), (0, 1, 0))
+    check(build(host.new_world(0)).render(cam, aux=True), build(_oracle().new_world()).render(cam, aux=True), f"{kind} {order}")
+
+
 def test_copies_of_a_triangle_in_parts():
     """The pass over the ids (k_copies_pixels) finds a pixel's ray from its row in the PART: interleaved parts of a
     frame whose every pixel needs the pass give the ids of the whole frame, which are the oracle's."""
