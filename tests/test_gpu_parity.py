@@ -1091,6 +1091,42 @@ def test_equal_solids_listed_more_than_once(kind, order, expected, grouped):
     check(build(host.new_world(0)).render(cam, aux=True), build(_oracle().new_world()).render(cam, aux=True), f"{kind} {order}")
 
 
+def _dup_glass_world(w, outer, inner, grouped, kind):
+    """`outer` glass solids in one place, `inner` denser ones half the size inside them, one more glass one after
+    those; a floor and a light."""
+    glass = B.Material(color=(0.1, 0.1, 0.1), diffuse=0.1, transparency=0.9, reflective=0.9, refractive_index=1.5)
+    dense = B.Material(color=(0.2, 0.1, 0.1), diffuse=0.2, transparency=0.8, reflective=0.3, refractive_index=2.0)
+    params = [-1.0, 1.0, 1.0] if kind in ("cylinder", "cone") else None
+    shapes = [w.shape(kind, (), glass, params=params) for _ in range(outer)]
+    shapes += [w.shape(kind, [("scale", 0.5, 0.5, 0.5)], dense, params=params) for _ in range(inner)]
+    shapes += [w.shape(kind, (), glass, params=params)]
+    if grouped:
+        g = w.group([("rotate-y", 0.3)])
+        for sh in shapes:
+            w.group_add_shape(g, sh)
+        w.add_group(g)
+    else:
+        for sh in shapes:
+            w.add_shape(sh)
+    w.add_shape(w.shape("plane", [("translate", 0, -1.5, 0)], B.Material(color=(0.9, 0.9, 0.5))))
+    w.add_point_light((-4, 6, -8), (1, 1, 1))
+    return w
+
+
+@pytest.mark.parametrize("kind,outer,inner,grouped", [("sphere", 1, 2, False), ("sphere", 2, 1, True), ("sphere", 3, 2, False),
+                                                      ("cube", 2, 2, True), ("cube", 3, 0, False), ("cylinder", 2, 1, False),
+                                                      ("cylinder", 1, 2, True)])
+def test_transparent_solids_listed_more_than_once(kind, outer, inner, grouped):
+    """n1 / n2 of Computations::prepare (intersections.rs:141-170) walk the list AFTER equal neighbours were dropped,
+    with `containers` compared by Shape ==: glass listed two and three times around denser glass listed twice gives the
+    oracle's colours, ids and ray counts (tools/gpu_dup_glass.py runs all 54 combinations)."""
+    cam = B.Camera(96, 72, 0.8, (0.5, 1.2, -5.0), (0, 0, 0), (0, 1, 0))
+    g = _dup_glass_world(host.new_world(0), outer, inner, grouped, kind).render(cam, aux=True)
+    r = _dup_glass_world(_oracle().new_world(), outer, inner, grouped, kind).render(cam, aux=True)
+    check(g, r, f"glass {kind} {outer} {inner} {grouped}")
+    assert g.stats["refract"] > 500
+
+
 def test_copies_of_a_triangle_in_parts():
     """The pass over the ids (k_copies_pixels) finds a pixel's ray from its row in the PART: interleaved parts of a
     frame whose every pixel needs the pass give the ids of the whole frame, which are the oracle's."""
