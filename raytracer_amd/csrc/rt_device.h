@@ -1250,9 +1250,10 @@ __device__ inline int next_copy(const Scene& sc, int s) {
 // A shape's own entries: the nearest in front of the origin (the hit, when the shape is the one hit) ...
 struct OwnHit {
   float t, u, v;
+  bool found;
   __device__ __forceinline__ bool takes(uint32_t) const { return true; }
   __device__ __forceinline__ void add(float tt, uint32_t, float uu, float vv) {
-    if (tt > 0.f && tt < t) t = tt, u = uu, v = vv;
+    if (tt > 0.f && (!found || tt < t)) found = true, t = tt, u = uu, v = vv;  // (t = +inf is a hit the reference shades)
   }
 };
 // ... and whether one of them is at t0 (with its (u, v))
@@ -1357,9 +1358,9 @@ __device__ inline int end_of_copy_run(const Scene& sc, const Ray& world, int w) 
   // the ray in the space of w's group, through the same chain of transforms as the walk (same bits), and the hit's t
   const int anchor = parent >= 0 ? cst(sc.nodes)[parent].next_xf : -1;
   const Ray local = anchor >= 0 ? ray_in_space_of<true>(sc, anchor, world) : world;
-  OwnHit own{__builtin_inff(), 0.f, 0.f};
+  OwnHit own{0.f, 0.f, 0.f, false};
   shape_intersect<false>(sc, (uint32_t)w, local, own);
-  if (!(own.t < __builtin_inff())) return w;  // (a hit at t = +inf is nobody's neighbour worth the search)
+  if (!own.found) return w;
   const float t0 = own.t, u0 = own.u, v0 = own.v;
   OrderWalk walk;
   walk.at = w;

@@ -1091,6 +1091,31 @@ def test_equal_solids_listed_more_than_once(kind, order, expected, grouped):
     check(build(host.new_world(0)).render(cam, aux=True), build(_oracle().new_world()).render(cam, aux=True), f"{kind} {order}")
 
 
+@pytest.mark.parametrize("grouped", [False, True])
+def test_equal_spheres_hit_at_infinity(grouped):
+    """A direction so short that dot(d, d) underflows gives t = +inf, a hit the reference shades (0 < inf), and equal
+    entries at inf are neighbours like any others: three spheres in one place report the third."""
+    def build(w):
+        shapes = [w.shape("sphere", (), None) for _ in range(3)]
+        if grouped:
+            g = w.group([("translate", 0, 0, 0)])
+            for sh in shapes:
+                w.group_add_shape(g, sh)
+            w.add_group(g)
+        else:
+            for sh in shapes:
+                w.add_shape(sh)
+        w.add_point_light((0, 5, -10), (1, 1, 1))
+        return w
+
+    o = np.array([[0, 0, -5.0]] * 4, dtype=np.float32)
+    d = np.array([[0, 0, 1e-23], [0, 0, 1e-22], [0, 0, 3e-23], [0, 0, 1.0]], dtype=np.float32)
+    _, gt, gid, _ = build(host.new_world(0)).color_at(o, d, 0)
+    _, rt_, rid, _ = build(_oracle().new_world()).color_at(o, d, 0)
+    assert np.array_equal(gid, rid) and np.array_equal(gt.view(np.uint32), rt_.view(np.uint32))
+    assert np.isinf(rt_[0]) and rid[0] == 2 and rid[3] == 2
+
+
 def _dup_glass_world(w, outer, inner, grouped, kind):
     """`outer` glass solids in one place, `inner` denser ones half the size inside them, one more glass one after
     those; a floor and a light."""
