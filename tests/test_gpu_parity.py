@@ -1116,6 +1116,47 @@ def test_equal_spheres_hit_at_infinity(grouped):
     assert np.isinf(rt_[0]) and rid[0] == 2 and rid[3] == 2
 
 
+@pytest.mark.parametrize("flags", [(False, True), (True, False), (False, False, True), (False, True, False)])
+@pytest.mark.parametrize("grouped", [False, True, "mesh", "in mesh"])
+def test_coincident_solids_that_differ_in_shadow(flags, grouped):
+    """World::is_shadowed looks at the closest hit only, and of hits at one t at the first listed (world.rs:101-111,
+    SURVEY.md Q5): a shadow-less sphere listed before a shadow-casting one in the same place casts no shadow, the other
+    order does.  (Two passes on the device: the nearest shadow-less hit, then any occluder before it in (t, rank).)"""
+    def build(w):
+        shapes = [w.shape("sphere", [("translate", 0, 1, 0)], B.Material(color=(0.3 + 0.2 * k, 0.5, 0.5)), shadow=f)
+                  for k, f in enumerate(flags)]
+        if grouped == "in mesh":  # coincident triangles inside the group whose auxiliary tree the shadow rays traverse
+            shapes = [w.shape("triangle", (), B.Material(color=(0.3 + 0.2 * k, 0.5, 0.5)), shadow=f,
+                              params=[-4, 3, -3, 3, 3, -3, 0, 3, 4]) for k, f in enumerate(flags)]
+        if grouped is True:
+            g = w.group([("translate", 0.5, 0, 0)])
+            for sh in shapes:
+                w.group_add_shape(g, sh)
+            w.add_group(g)
+        elif grouped != "in mesh":
+            for sh in shapes:
+                w.add_shape(sh)
+        if grouped in ("mesh", "in mesh"):  # a mesh with an auxiliary tree: the shadow rays take the two-pass search
+            from raytracer_amd import synth
+            m = synth.synth_dragon(50, 50)[0]
+            gm = w.group([("scale", 0.4, 0.4, 0.4), ("translate", 2.2, 0.8, 0.5)])
+            w.group_add_mesh(gm, B.Material(color=(0.8, 0.3, 0.2)), m["positions"], m["normals"], m["vidx"], m["nidx"])
+            if grouped == "in mesh":
+                for sh in shapes:
+                    w.group_add_shape(gm, sh)
+            w.group_divide(gm, 50)
+            w.add_group(gm)
+        w.add_shape(w.shape("plane", (), B.Material(color=(0.9, 0.9, 0.9))))
+        w.add_point_light((-3, 6, -4), (1, 1, 1))
+        return w
+
+    cam = B.Camera(80, 60, 0.9, (0.5, 3.0, -6.0), (0.5, 0.5, 0.0), (0, 1, 0))
+    g = build(host.new_world(0)).render(cam, aux=True)
+    r = build(_oracle().new_world()).render(cam, aux=True)
+    check(g, r, f"shadow flags {flags}")
+    assert np.array_equal(to_u8(g.rgb), to_u8(r.rgb))
+
+
 def _dup_glass_world(w, outer, inner, grouped, kind):
     """`outer` glass solids in one place, `inner` denser ones half the size inside them, one more glass one after
     those; a floor and a light."""
