@@ -1116,6 +1116,57 @@ def test_equal_spheres_hit_at_infinity(grouped):
     assert np.isinf(rt_[0]) and rid[0] == 2 and rid[3] == 2
 
 
+@pytest.mark.parametrize("op", ["union", "intersect", "difference"])
+@pytest.mark.parametrize("kind", ["sphere", "cube", "cylinder"])
+@pytest.mark.parametrize("same", [True, False])
+def test_csg_of_coincident_solids(op, kind, same):
+    """A csg of two solids in the very same place (equal shapes, or equal but for the material): every crossing is a
+    tie of a left and a right entry, and the filter sees them in list order after equal neighbours were dropped
+    (csg.rs:26-72); nested once more with a sphere, and a loose copy of the solid behind."""
+    ops = {"union": B.CSG_UNION, "intersect": B.CSG_INTERSECT, "difference": B.CSG_DIFFERENCE}
+    params = [-1.0, 1.0, 1.0] if kind == "cylinder" else None
+
+    def build(w):
+        a = B.Material(color=(0.9, 0.3, 0.3))
+        b = a if same else B.Material(color=(0.3, 0.9, 0.3))
+        left = w.shape(kind, [("rotate-y", 0.4)], a, params=params)
+        right = w.shape(kind, [("rotate-y", 0.4)], b, params=params)
+        c = w.csg(ops[op], B.CHILD_SHAPE, left, B.CHILD_SHAPE, right)
+        ball = w.shape("sphere", [("scale", 0.7, 0.7, 0.7), ("translate", 0.6, 0.5, -0.5)], B.Material(color=(0.3, 0.3, 0.9)))
+        w.add_csg(w.csg(B.CSG_DIFFERENCE, B.CHILD_CSG, c, B.CHILD_SHAPE, ball))
+        w.add_shape(w.shape(kind, [("rotate-y", 0.4)], a, params=params))
+        w.add_shape(w.shape("plane", [("translate", 0, -1.5, 0)], B.Material(color=(0.9, 0.9, 0.5))))
+        w.add_point_light((-4, 6, -8), (1, 1, 1))
+        return w
+
+    cam = B.Camera(96, 72, 0.8, (0.5, 1.2, -5.0), (0, 0, 0), (0, 1, 0))
+    g = build(host.new_world(0)).render(cam, aux=True)
+    r = build(_oracle().new_world()).render(cam, aux=True)
+    check(g, r, f"csg {op} {kind} {same}")
+
+
+@pytest.mark.parametrize("order", ["ab", "ba", "aba", "abab", "aabb"])
+@pytest.mark.parametrize("kind", ["sphere", "cube"])
+def test_coincident_glass_of_different_refractive_index(order, kind):
+    """Two kinds of glass in the very same place: every surface is a tie of entries of different shapes, taken in
+    list order (stable sort) by `hit` and by the containers of n1 / n2 (intersections.rs:141-170)."""
+    mats = {"a": B.Material(color=(0.1, 0.1, 0.1), diffuse=0.1, transparency=0.9, reflective=0.5, refractive_index=1.5),
+            "b": B.Material(color=(0.1, 0.2, 0.1), diffuse=0.1, transparency=0.8, reflective=0.3, refractive_index=2.0)}
+
+    def build(w):
+        for c in order:
+            w.add_shape(w.shape(kind, [("rotate-y", 0.4)], mats[c]))
+        w.add_shape(w.shape("plane", [("translate", 0, -1.5, 0)], B.Material(color=(0.9, 0.9, 0.5))))
+        w.add_point_light((-4, 6, -8), (1, 1, 1))
+        return w
+
+    cam = B.Camera(96, 72, 0.8, (0.5, 1.2, -5.0), (0, 0, 0), (0, 1, 0))
+    g = build(host.new_world(0)).render(cam, aux=True)
+    r = build(_oracle().new_world()).render(cam, aux=True)
+    check(g, r, f"coincident glass {kind} {order}")
+    assert g.stats["refract"] > 500
+
+
 @pytest.mark.parametrize("flags", [(False, True), (True, False), (False, False, True), (False, True, False)])
 @pytest.mark.parametrize("grouped", [False, True, "mesh", "in mesh"])
 def test_coincident_solids_that_differ_in_shadow(flags, grouped):
