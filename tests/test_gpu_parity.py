@@ -1116,6 +1116,43 @@ def test_equal_spheres_hit_at_infinity(grouped):
     assert np.isinf(rt_[0]) and rid[0] == 2 and rid[3] == 2
 
 
+@pytest.mark.parametrize("n,threshold", [(48, 6), (96, 20)])
+def test_rays_through_the_edges_and_corners_of_a_mesh(n, threshold):
+    """A flat n x n grid of quads at dyadic coordinates, divided, under an auxiliary tree: rays straight down the grid
+    lines meet two triangles (an edge) or up to six (a corner) at the very same t, in different leaves of the tree,
+    and the hit is the one listed first -- the (t, rank) order of the traversal's hit keys."""
+    xs = (np.arange(n + 1, dtype=np.float32) - n / 2) / 8.0
+    gx, gy = np.meshgrid(xs, xs, indexing="ij")
+    positions = np.stack([gx.ravel(), gy.ravel(), np.zeros((n + 1) ** 2, dtype=np.float32)], axis=1)
+    normals = np.tile(np.array([[0, 0, -1]], dtype=np.float32), (len(positions), 1))
+    iu, iv = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+    a, b_, c, d_ = iu * (n + 1) + iv, (iu + 1) * (n + 1) + iv, (iu + 1) * (n + 1) + iv + 1, iu * (n + 1) + iv + 1
+    vidx = np.concatenate([np.stack([a, b_, c], axis=-1).reshape(-1, 3), np.stack([a, c, d_], axis=-1).reshape(-1, 3)]).astype(np.int32)
+    rng = np.random.RandomState(n)
+    vidx = vidx[rng.permutation(len(vidx))]  # neighbours far apart in the list: the ranks decide, not the leaves
+
+    def build(w):
+        g = w.group([("translate", 0.25, -0.5, 0)])
+        w.group_add_mesh(g, B.Material(color=(0.8, 0.4, 0.2)), positions, normals, vidx, vidx)
+        w.group_divide(g, threshold)
+        w.add_group(g)
+        w.add_point_light((0, 5, -10), (1, 1, 1))
+        return w
+
+    half = (np.arange(2 * n + 1, dtype=np.float32) - n) / 16.0  # grid lines and the middles between them
+    px, py = np.meshgrid(half, half, indexing="ij")
+    o = np.stack([px.ravel() + 0.25, py.ravel() - 0.5, np.full(px.size, -5.0, dtype=np.float32)], axis=1).astype(np.float32)
+    d = np.tile(np.array([[0, 0, 1.0]], dtype=np.float32), (len(o), 1))
+    gw, ow = build(host.new_world(0)), build(_oracle().new_world())
+    assert gw.device_scene() and host.hip_lib()
+    _, gt, gid, guv = gw.color_at(o, d, 0)
+    _, rt_, rid, ruv = ow.color_at(o, d, 0)
+    assert (rid >= 0).mean() > 0.9 and np.array_equal(gid, rid)
+    hit = rid >= 0
+    assert np.array_equal(gt[hit].view(np.uint32), rt_[hit].view(np.uint32))
+    assert np.array_equal(guv[hit].view(np.uint32), ruv[hit].view(np.uint32))
+
+
 @pytest.mark.parametrize("op", ["union", "intersect", "difference"])
 @pytest.mark.parametrize("kind", ["sphere", "cube", "cylinder"])
 @pytest.mark.parametrize("same", [True, False])
