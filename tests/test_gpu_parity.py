@@ -1116,6 +1116,27 @@ def test_equal_spheres_hit_at_infinity(grouped):
     assert np.isinf(rt_[0]) and rid[0] == 2 and rid[3] == 2
 
 
+@pytest.mark.parametrize("order,expected", [("aaa", 2), ("aba", 0), ("aab", 1)])
+@pytest.mark.parametrize("cells", [2, 4])
+def test_equal_solids_under_an_area_light(order, expected, cells):
+    """The same rule through the direct kernels (group-less worlds under a multi-sample area light: k_render_direct,
+    hoisted for worlds of a few shapes): they write the winner's id and the pass over the ids follows."""
+    def build(w):
+        for c in order:
+            w.add_shape(w.shape("sphere", [("translate", 0, 1, 0)], B.Material(color=(1, 0.2, 0.2) if c == "a" else (0.2, 1, 0.2))))
+        w.add_shape(w.shape("plane", (), B.Material(color=(0.9, 0.9, 0.9))))
+        w.add_area_light((-3, 6, -4), (2, 0, 0), cells, (0, 0, 2), cells, (1, 1, 1))
+        return w
+
+    cam = B.Camera(80, 60, 0.9, (0.5, 3.0, -6.0), (0.5, 0.5, 0.0), (0, 1, 0))
+    ro = B.RenderOptions(jitter_mode=B.JITTER_COUNTER, seed=3)
+    g = build(host.new_world(0)).render(cam, ro, aux=True)
+    r = build(_oracle().new_world()).render(cam, ro, aux=True)
+    check(g, r, f"area light {order}")
+    ids = set(np.unique(r.object_id)) - {-1}
+    assert ids == {expected, len(order)}  # the spheres' entry and the floor
+
+
 @pytest.mark.parametrize("n,threshold", [(48, 6), (96, 20)])
 def test_rays_through_the_edges_and_corners_of_a_mesh(n, threshold):
     """A flat n x n grid of quads at dyadic coordinates, divided, under an auxiliary tree: rays straight down the grid
