@@ -1116,6 +1116,35 @@ def test_equal_spheres_hit_at_infinity(grouped):
     assert np.isinf(rt_[0]) and rid[0] == 2 and rid[3] == 2
 
 
+def test_the_bound_on_the_search_between_copies():
+    """The one bound of the pass over the ids (RT_COPY_GAP_MAX = 65 536 intersections per hit, rt_device.h): a triangle
+    listed again 70 000 places on in ONE undivided group.  The reference reports the later copy; the device stops its
+    search where the budget ends and reports the winner -- the id only: t is the same.  With
+    60 000 between them the search gets there."""
+    def world(w, between):
+        far = np.zeros((between, 3, 3), dtype=np.float32)
+        far[:, :, 0] = 100.0 + np.arange(between, dtype=np.float32)[:, None] * 0.01
+        far[:, 1, 1] = 1.0
+        far[:, 2, 2] = 1.0
+        tri = np.array([[0, 0, 0], [4, 0, 0], [0, 4, 0]], dtype=np.float32)
+        corners = np.concatenate([tri[None], far, tri[None]])
+        positions = corners.reshape(-1, 3)
+        vidx = np.arange(len(positions), dtype=np.int32).reshape(-1, 3)
+        g = w.group(())
+        w.group_add_mesh(g, None, positions, None, vidx, None)
+        w.add_group(g)
+        w.add_point_light((0, 5, 10), (1, 1, 1))
+        return w
+
+    o = np.array([[1.0, 1.0, 5.0]], dtype=np.float32)
+    d = np.array([[0.0, 0.0, -1.0]], dtype=np.float32)
+    for between, expected in ((60000, 60001), (70000, 0)):
+        _, gt, gid, _ = world(host.new_world(0), between).color_at(o, d, 0)
+        _, rt_, rid, _ = world(_oracle().new_world(), between).color_at(o, d, 0)
+        assert gt[0] == rt_[0] == 5.0 and rid[0] == between + 1
+        assert gid[0] == expected
+
+
 @pytest.mark.parametrize("order,expected", [("aaa", 2), ("aba", 0), ("aab", 1)])
 @pytest.mark.parametrize("cells", [2, 4])
 def test_equal_solids_under_an_area_light(order, expected, cells):
